@@ -1,0 +1,219 @@
+"""ORACLE -- test infrastructure only, never part of the product path.
+
+A plain PyTorch-CPU fp32 restatement of the reference hot path, in the reference's own
+(literal) association: the [B,T,H,4D] concat is materialised exactly as the reference
+does.  It exists to (1) be pinned against the real reference in this container by
+``oracle/make_golden.py`` (which also writes tests/golden/*.npz), (2) check the HIP path in
+``tests/`` and ``__graft_entry__.smoke()``, and (3) be timed as the ``cpu_baseline`` leg of
+``bench.py``.  Only those three may import it.  Parity status: PINNED -- every function below is
+compared with the imported reference model on seeded inputs by make_golden.py (max abs
+difference recorded in tests/golden/MANIFEST.json).
+
+Parameters are a flat dict keyed by the reference's ``state_dict`` names.
+All citations are relative to /root/reference.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------- building blocks
+def mlp(p, prefix, x):
+    """Linear(d -> d//4) -> exact-erf GELU -> Linear(d//4 -> out).  models/attention_model.py:29-32
+    (activation default 'gelu' = nn.GELU(), :21,27)."""
+    hid = F.linear(x, p[prefix + ".fc1.weight"], p[prefix + ".fc1.bias"])
+    hid = 0.5 * hid * (1.0 + torch.erf(hid * (1.0 / math.sqrt(2.0))))
+    return F.linear(hid, p[prefix + ".fc2.weight"], p[prefix + ".fc2.bias"])
+
+
+def pointwise_attention_scores(p, prefix, target, history):
+    """score[b,t,h] = MLP(cat[h, t, t-h, t*h]) -> [B,T,H,1].  models/attention_model.py:52-97.
+    A 2-D target [B,D] is treated as T=1 (:64-65)."""
+    if target.dim() == 2:
+        target = target[:, None, :]
+    B, T, D = target.shape
+    H = history.shape[1]
+    te = target[:, :, None, :].expand(B, T, H, D)
+    he = history[:, None, :, :].expand(B, T, H, D)
+    feats = torch.cat([he, te, te - he, te * he], dim=-1)          # :81-86, order matters
+    s = mlp(p, prefix + ".mlp", feats.reshape(-1, 4 * D))          # :89-92
+    return s.reshape(B, T, H, 1)                                   # :95
+
+
+def _split_cols(x, widths):
+    out, c = [], 0
+    for w in widths:
+        out.append(x[:, :, c:c + w])
+        c += w
+    return out
+
+
+def _label_features(p, category, sub_category, sentiment, typ):
+    """models/user_invariant_interest_model.py:58-64.  The category table serves both the category
+    and the (mean of the) sub-category ids; the mean includes padding id 0."""
+    inv = "invariant_interest_model."
+    table = p[inv + "category_embedding.0.weight"]
+    cat = table[category[..., 0].long()]                           # [B,N,e0]
+    sub = table[sub_category.long()].mean(dim=2)                   # [B,N,5,e0] -> mean over 5
+    sen = torch.relu(F.linear(sentiment, p[inv + "sentiment_embedding.0.weight"],
+                              p[inv + "sentiment_embedding.0.bias"]))
+    typ_e = p[inv + "type_embedding.0.weight"][typ[..., 0].long()]
+    return torch.cat([cat + sub, sen, typ_e], dim=2)
+
+
+def _time_features(p, time4):
+    """Sum of the year/month/day/hour lookups.  models/user_invariant_interest_model.py:66-71."""
+    inv = "invariant_interest_model."
+    out = 0
+    for i, name in enumerate(("year", "month", "day", "hour")):
+        out = out + p[inv + name + "_embedding.0.weight"][time4[..., i].long()]
+    return out
+
+
+def invariant_interest(p, x_history, x_target, n_sub=5, n_sent=3, return_aux=False):
+    """(eu_H, ec).  models/user_invariant_interest_model.py:73-89."""
+    inv = "invariant_interest_model."
+    P = p[inv + "text_img_attention.mlp.fc2.weight"].shape[1]
+    widths = [4, P, 1, n_sub, n_sent, 1, 1, 1]
+    time_h, ti_h, cat_h, sub_h, sen_h, typ_h, read_h, scroll_h = _split_cols(x_history.float(), widths)
+    time_t, ti_t, cat_t, sub_t, sen_t, typ_t = _split_cols(x_target.float(), widths[:6])
+
+    lab_h = torch.cat([_label_features(p, cat_h, sub_h, sen_h, typ_h), _time_features(p, time_h),
+                       read_h, scroll_h], dim=2)                                   # :77
+    lab_h = F.linear(lab_h, p[inv + "w1.weight"], p[inv + "w1.bias"])              # :78
+    lab_t = torch.cat([_label_features(p, cat_t, sub_t, sen_t, typ_t), _time_features(p, time_t)], dim=2)  # :79
+    ec = torch.cat([lab_t, ti_t], dim=2)                                           # :81
+
+    s_lab = pointwise_attention_scores(p, inv + "label_attention", lab_t, lab_h)   # :83
+    s_ti = pointwise_attention_scores(p, inv + "text_img_attention", ti_t, ti_h)   # :84
+    pooled_lab = torch.sum(s_lab * lab_h[:, None], dim=2)                          # :86 (no softmax, no mask)
+    pooled_ti = torch.sum(s_ti * ti_h[:, None], dim=2)                             # :87
+    eu_H = torch.cat([pooled_lab, pooled_ti], dim=2)                               # :88
+    if return_aux:
+        return eu_H, ec, {"score_label": s_lab, "score_text_img": s_ti, "label_h": lab_h, "label_t": lab_t}
+    return eu_H, ec
+
+
+def instant_interest(p, x_global):
+    """ReLU(Linear(3->8)).  models/user_instant_interest_model.py:20-23."""
+    return torch.relu(F.linear(x_global.float(), p["instant_interest_model.out_fc.0.weight"],
+                               p["instant_interest_model.out_fc.0.bias"]))
+
+
+def user_model_forward(p, x_history, x_target, x_global, training=True, bn_state=None,
+                       momentum=0.1, eps=1e-5, return_aux=False):
+    """r[B,T].  models/user_model.py:27-35.  ``bn_state`` (dict with running_mean/var,
+    num_batches_tracked) is updated in place when training, as nn.BatchNorm1d does."""
+    eu_H, ec, aux = invariant_interest(p, x_history, x_target, return_aux=True)
+    eu_L = instant_interest(p, x_global)
+    e = torch.cat([eu_H, eu_L, ec], dim=2)                         # :31
+    B, T, N = e.shape
+    e2 = e.reshape(B * T, N)
+    if training:
+        mean = e2.mean(dim=0)
+        var_b = e2.var(dim=0, unbiased=False)
+        if bn_state is not None:
+            with torch.no_grad():
+                n = e2.shape[0]
+                bn_state["running_mean"].mul_(1 - momentum).add_(momentum * mean)
+                bn_state["running_var"].mul_(1 - momentum).add_(momentum * var_b * n / max(n - 1, 1))
+                bn_state["num_batches_tracked"] += 1
+    else:
+        mean, var_b = p["bn.running_mean"], p["bn.running_var"]
+    c = (e2 - mean) / torch.sqrt(var_b + eps) * p["bn.weight"] + p["bn.bias"]   # :32
+    x = mlp(p, "gate", c) * e2                                     # :33  (gate multiplies the RAW concat)
+    r = mlp(p, "out_mlp", mlp(p, "mlp", x)).reshape(B, T)          # :33-34
+    if return_aux:
+        aux.update({"eu_H": eu_H, "ec": ec, "eu_L": eu_L})
+        return r, aux
+    return r
+
+
+def bce_mean(prob, y):
+    """nn.BCELoss(): mean of -(y log p + (1-y) log(1-p)) with both logs clamped at -100."""
+    lp = torch.clamp(torch.log(prob), min=-100.0)
+    l1p = torch.clamp(torch.log(1.0 - prob), min=-100.0)
+    return -(y * lp + (1.0 - y) * l1p).mean()
+
+
+def user_model_loss(p, user_id, out, label, alpha=0.95):
+    """(1-alpha)*BCE(softmax_T(out)) + alpha*BCE(softmax_T(out + delta[id])).  models/user_model.py:37-43."""
+    y = label.float()
+    l1 = bce_mean(torch.softmax(out, dim=1), y)
+    d = p["delta"][user_id.long()][:, None].expand(-1, y.shape[1])
+    l2 = bce_mean(torch.softmax(out + d, dim=1), y)
+    return (1 - alpha) * l1 + alpha * l2
+
+
+# --------------------------------------------------------------------------- the train.py:66-75 step
+BUFFER_KEYS = ("bn.running_mean", "bn.running_var", "bn.num_batches_tracked")
+
+
+def to_torch_params(sd_np, requires_grad=True):
+    p = {}
+    for k, v in sd_np.items():
+        t = torch.from_numpy(np.array(v, copy=True))
+        if k not in BUFFER_KEYS and requires_grad:
+            t.requires_grad_(True)
+        p[k] = t
+    return p
+
+
+def adam_update(param, grad, m, v, step, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, weight_decay=1e-5):
+    """torch.optim.Adam semantics used at train.py:48 (L2 folded into the gradient, bias-corrected,
+    eps added after the sqrt of the corrected second moment)."""
+    g = grad + weight_decay * param
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    param.addcdiv_(m, denom, value=-lr / bc1)
+
+
+def train_step(p, opt_state, batch, lr=1e-3, weight_decay=1e-5, alpha=0.95):
+    """forward -> loss -> backward -> Adam step -> zero_grad (train.py:69-75), train-mode BN.
+    ``p`` holds leaf tensors (updated in place); ``opt_state`` = {"step": int, "m": {}, "v": {}}.
+    Returns (loss, r, grads)."""
+    bn_state = {k.split(".")[1]: p[k] for k in BUFFER_KEYS}
+    r = user_model_forward(p, batch["x_history"], batch["x_target"], batch["x_global"],
+                           training=True, bn_state=bn_state)
+    loss = user_model_loss(p, batch["user_id"], r, batch["label"], alpha)
+    names = [k for k in p if k not in BUFFER_KEYS]
+    grads = torch.autograd.grad(loss, [p[k] for k in names], allow_unused=True)
+    opt_state["step"] += 1
+    gout = {}
+    with torch.no_grad():
+        for k, g in zip(names, grads):
+            if g is None:
+                g = torch.zeros_like(p[k])
+            gout[k] = g
+            if k not in opt_state["m"]:
+                opt_state["m"][k] = torch.zeros_like(p[k])
+                opt_state["v"][k] = torch.zeros_like(p[k])
+            adam_update(p[k], g, opt_state["m"][k], opt_state["v"][k], opt_state["step"],
+                        lr=lr, weight_decay=weight_decay)
+    return loss.detach(), r.detach(), gout
+
+
+# --------------------------------------------------------------------------- per-row AUC (train.py:77-80)
+def row_auc(label_row, score_row):
+    """Binary ROC-AUC of one impression = Mann-Whitney U with tie-averaged ranks, which is what
+    sklearn.metrics.roc_auc_score (tool/evaluation.py:3-5) returns for binary labels."""
+    y = np.asarray(label_row, dtype=np.float64) > 0.5
+    s = np.asarray(score_row, dtype=np.float64)
+    n_pos, n_neg = int(y.sum()), int((~y).sum())
+    if n_pos == 0 or n_neg == 0:
+        raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
+    pos, neg = s[y], s[~y]
+    gt = (pos[:, None] > neg[None, :]).sum()
+    eq = (pos[:, None] == neg[None, :]).sum()
+    return float(gt + 0.5 * eq) / float(n_pos * n_neg)
+
+
+def batch_auc(label, score):
+    return np.array([row_auc(label[b], score[b]) for b in range(label.shape[0])])
