@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- train impressions/sec of the UserModel hot path on synthetic EBNeRD-shaped batches.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3-large]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is the reference's train.py:66-75 on one batch: forward -> loss -> backward -> [one gradient
+all-reduce when N > 1] -> Adam(lr 1e-3, weight_decay 1e-5) -> zero_grad, train-mode BatchNorm, inputs
+resident in HBM as fp32.  Every rank holds its own batch of B impressions (weak scaling: global batch
+N*B, BASELINE config 4 at N=8).  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline      the dominant HIP kernel (largest summed time in the timed region): algorithmic FLOPs per
+                launch (2*B*T*H*D^2, the contraction only) / its mean launch duration measured
+                with HIP events on the launch stream, against the dense fp32 MFMA peak of gfx950.
+  cpu_baseline  the oracle (PyTorch-CPU restatement of the reference-literal algorithm) timed on this box's
+                host cores on a bounded sample of the same workload (reduced B), rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="C3-large")
+    ap.add_argument("--batch", type=int, default=None, help="override per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=None)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(dims, wl, seconds, cpu_batch):
+    """Oracle train step (reference-literal: materialises the [B,T,H,4D] concat) on the host cores."""
+    from news_recommendation_model_amd import synth
+    from oracle import user_model_oracle as orc
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    # bounded sample: concat bytes = B*T*H*4D*4 per attention; keep it around 0.25 GB
+    per_imp = wl["T"] * wl["H"] * 4 * wl["emb"] * 4
+    Bc = cpu_batch or int(max(2, min(wl["B"], (256 << 20) // per_imp)))
+    batch = synth.make_batch(dims, Bc, wl["H"], wl["T"], seed=0)
+    sd = synth.make_state_dict(dims, seed=1, user_num=int(batch["user_num"]), perturb=False)
+    p = orc.to_torch_params(sd)
+    tb = {k: torch.from_numpy(v) for k, v in batch.items() if isinstance(v, np.ndarray) and v.ndim > 0}
+    tb = {k: (v.float() if v.is_floating_point() else v) for k, v in tb.items()}
+    st = {"step": 0, "m": {}, "v": {}}
+    orc.train_step(p, st, tb)                       # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.train_step(p, st, tb)
+        n += 1
+        el = time.perf_counter() - t0
+        if (el >= seconds and n >= 3) or el > 3 * seconds:
+            break
+    return {"value": round(Bc * n / el, 2), "unit": "impressions/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/user_model_oracle.train_step, B={Bc} H={wl['H']} T={wl['T']} D={wl['emb']}, "
+                      f"{n} steps after 1 warm-up, torch CPU fp32 {cores} threads"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from news_recommendation_model_amd import native, synth, trainer
+    from news_recommendation_model_amd.config import Dims, WORKLOADS
+    native.load()
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl["B"] = args.batch
+    B, H, T, D = wl["B"], wl["H"], wl["T"], wl["emb"]
+    dims = Dims.for_emb(D)
+    user_num = 10 * B
+    # same weights on every rank (seed 1), a different batch per rank (seed = rank)
+    sd = synth.make_state_dict(dims, seed=1, user_num=user_num, perturb=False)
+    model = trainer.build_model(dims, user_num, sd, device=dev).train()
+    opt = trainer.make_optimizer(model)
+    reducer = trainer.FlatGradReducer(model.parameters()) if world > 1 else None
+    batch = synth.make_batch(dims, B, H, T, seed=rank, user_num=user_num, dtype=np.float32)
+    tb = trainer.batch_to_device(batch, dev)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.train_step(model, opt, tb, reducer)
+    sync()
+    native.kernel_events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = trainer.train_step(model, opt, tb, reducer)
+    sync()
+    elapsed = time.perf_counter() - t0
+    events, native.kernel_events = native.kernel_events, None
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # per-kernel launch durations from the event pairs recorded on the launch stream
+    per = {}
+    for tag, e0, e1 in events:
+        per.setdefault(tag, []).append(e0.elapsed_time(e1))
+    kern = {k: {"launches": len(v), "mean_ms": float(np.mean(v)), "total_ms": float(np.sum(v))} for k, v in per.items()}
+    heavy = {k: v for k, v in kern.items() if k in ("nrm_pwattn_fwd", "pwattn_bwd_e_bt", "pwattn_bwd_e_bh")}
+    dom = max(heavy, key=lambda k: heavy[k]["total_ms"])
+    flops_per_launch = 2.0 * B * T * H * D * D            # both attentions have width D in BASELINE shapes
+    achieved = flops_per_launch / (heavy[dom]["mean_ms"] * 1e-3) / 1e12
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        line = {
+            "metric": "train impressions/sec", "value": round(world * B * args.steps / elapsed, 2),
+            "unit": "impressions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: EBNeRD-large-shape synthetic" if args.workload == "C3-large" else args.workload,
+                       "per_gpu_batch": B, "global_batch": world * B, "hist": H, "candidates": T, "emb": D,
+                       "user_num": user_num, "parallelism": f"dp{world}",
+                       "step": "fwd+loss+bwd+allreduce+Adam(wd=1e-5)" if world > 1 else "fwd+loss+bwd+Adam(wd=1e-5)"},
+            "loss": round(float(loss), 6),
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "flops_per_launch": flops_per_launch, "mean_launch_ms": round(heavy[dom]["mean_ms"], 4)},
+            "kernels": {k: {"launches": v["launches"], "mean_ms": round(v["mean_ms"], 4)} for k, v in kern.items()},
+            "grad_allreduce_bytes": reducer.nbytes if reducer else 0,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(dims, wl, args.cpu_seconds, args.cpu_batch)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

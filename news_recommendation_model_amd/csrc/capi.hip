@@ -1,0 +1,111 @@
+// extern "C" entry points declared in include/nrm_hotpath.h: host-side validation + launches only.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/nrm_hotpath.h"
+#include "pwattn.hpp"
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+static int check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return NRM_OK;
+    return fail(NRM_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+}
+
+// waves the E-form kernels aim to keep in flight: 256 CUs x 4 SIMDs x 2 waves
+static const int kTargetWaves = 2048;
+
+static int check_dims(const char* fn, int B, int T, int H, int D) {
+    if (B < 0 || T <= 0 || H <= 0 || D <= 0) return fail(NRM_EINVAL, "%s: B=%d T=%d H=%d D=%d must be positive", fn, B, T, H, D);
+    if (D % 4) return fail(NRM_EINVAL, "%s: D=%d must be a multiple of 4", fn, D);
+    if (D > 1024) return fail(NRM_EINVAL, "%s: D=%d > 1024 not supported", fn, D);
+    const long M = (long)B * T * H;
+    if (M >= (1L << 31) / 1 || (long)B * T * D >= (1L << 31) || (long)B * H * D >= (1L << 31))
+        return fail(NRM_EINVAL, "%s: B*T*H=%ld (or a [B,T,D]/[B,H,D] operand) exceeds 2^31 elements", fn, M);
+    return NRM_OK;
+}
+
+extern "C" {
+
+int nrm_abi_version(void) { return NRM_ABI_VERSION; }
+const char* nrm_last_error(void) { return g_err; }
+
+long nrm_pwattn_packed_floats(int D) {
+    if (D <= 0) return 0;
+    const nrm::FwdPlan pl = nrm::pwattn_fwd_plan(D);
+    return (long)pl.kchunks * pl.rows * 16 + 256 * 4 * 2;   // + over-read pad of the staging loop
+}
+
+int nrm_pwattn_pack_wp(const float* fc1_weight, int ld, int D, float* packed, nrm_stream_t stream) {
+    if (!fc1_weight || !packed) return fail(NRM_EINVAL, "nrm_pwattn_pack_wp: null pointer");
+    if (D <= 0 || D % 4 || ld < 4 * D) return fail(NRM_EINVAL, "nrm_pwattn_pack_wp: D=%d ld=%d (need D%%4==0, ld>=4D)", D, ld);
+    const nrm::FwdPlan pl = nrm::pwattn_fwd_plan(D);
+    return check_hip(nrm::pack_wp_launch(fc1_weight + 3 * (long)D, ld, D, pl, packed, (hipStream_t)stream), "pack_wp");
+}
+
+int nrm_pwattn_fwd(const float* t, const float* h, const float* u, const float* v, const float* packed_wp,
+                   const float* w2, const float* b2, float* z, float* s,
+                   int B, int T, int H, int D, nrm_stream_t stream) {
+    if (int rc = check_dims("nrm_pwattn_fwd", B, T, H, D)) return rc;
+    if (!t || !h || !u || !v || !packed_wp || !w2 || !b2 || !s) return fail(NRM_EINVAL, "nrm_pwattn_fwd: null pointer");
+    if (B == 0) return NRM_OK;
+    const nrm::FwdPlan pl = nrm::pwattn_fwd_plan(D);
+    nrm::FwdParams p;
+    p.t = t; p.h = h; p.u = u; p.v = v; p.wp = packed_wp; p.w2 = w2; p.b2 = b2; p.z = z; p.s = s;
+    p.M = (long)B * T * H; p.T = T; p.H = H; p.D = D;
+    p.ldt = D; p.ldh = D; p.ldu = D; p.ldv = D;
+    p.rows = pl.rows; p.kchunks = pl.kchunks; p.nchunks = pl.nchunks;
+    return check_hip(nrm::pwattn_fwd_launch(p, pl, (hipStream_t)stream), "pwattn_fwd");
+}
+
+int nrm_pwattn_bwd_dz(float* z_inout, const float* ds, const float* w2, float* dw2, long M, int D, nrm_stream_t stream) {
+    if (!z_inout || !ds || !w2 || !dw2) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dz: null pointer");
+    if (M < 0 || D <= 0 || D % 4 || D > 1024) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dz: M=%ld D=%d", M, D);
+    return check_hip(nrm::bwd_dz_launch(z_inout, ds, w2, dw2, M, D, (hipStream_t)stream), "bwd_dz");
+}
+
+int nrm_pwattn_bwd_nsplit(int B, int T, int H, int D) {
+    if (B <= 0 || T <= 0 || H <= 0 || D <= 0) return 0;
+    return nrm::bwd_e_plan(D, B * T, kTargetWaves).nsplit;
+}
+
+int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, const float* wp, int ldwp,
+                            float* dt, float* dh, float* ws, int B, int T, int H, int D, int passes, nrm_stream_t stream) {
+    if (int rc = check_dims("nrm_pwattn_bwd_contract", B, T, H, D)) return rc;
+    if (!dz || !t || !h || !wp) return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: null pointer");
+    if (passes < 1 || passes > 3) return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: passes=%d", passes);
+    if (((passes & 1) && (!dt || !ws)) || ((passes & 2) && !dh)) return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: null output");
+    if (ldwp < D || ldwp % 4) return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: ldwp=%d", ldwp);
+    if (B == 0) return NRM_OK;
+    const long HD = (long)H * D, TD = (long)T * D;
+    // pass 1: groups (b,t); rows r = h.  X_g = dz[b,t,:,:], Y_g = h[b];  out = dt, scale rows = t
+    if (passes & 1) {
+        nrm::BwdEParams p = {};
+        p.X = dz; p.xs1 = (long)T * HD; p.xs2 = HD; p.xrs = D;
+        p.Y = h; p.ys1 = HD; p.yrs = D;
+        p.wp = wp; p.ldwp = ldwp; p.srow = t; p.lds_ = D; p.out = dt; p.ldo = D; p.ws = ws;
+        p.G = B * T; p.G2 = T; p.R = H; p.D = D;
+        const nrm::BwdEPlan pl = nrm::bwd_e_plan(D, p.G, kTargetWaves);
+        if (int rc = check_hip(nrm::bwd_e_launch(p, pl, true, (hipStream_t)stream), "bwd_e pass 1")) return rc;
+    }
+    // pass 2: groups (b,h); rows r = t.  X_g = dz[b,:,h,:], Y_g = t[b];  out = dh
+    if (passes & 2) {
+        nrm::BwdEParams p = {};
+        p.X = dz; p.xs1 = (long)T * HD; p.xs2 = D; p.xrs = HD;
+        p.Y = t; p.ys1 = TD; p.yrs = D;
+        p.wp = wp; p.ldwp = ldwp; p.srow = nullptr; p.lds_ = 0; p.out = dh; p.ldo = D; p.ws = nullptr;
+        p.G = B * H; p.G2 = H; p.R = T; p.D = D;
+        const nrm::BwdEPlan pl = nrm::bwd_e_plan(D, p.G, kTargetWaves);
+        if (int rc = check_hip(nrm::bwd_e_launch(p, pl, false, (hipStream_t)stream), "bwd_e pass 2")) return rc;
+    }
+    return NRM_OK;
+}
+
+}  // extern "C"

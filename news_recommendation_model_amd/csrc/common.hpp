@@ -1,0 +1,60 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the UserModel hot path.
+// fp32 everywhere: the matrix work runs on v_mfma_f32_16x16x4_f32 (exact f32 FMA chains).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nrm {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int WAVE = 64;
+
+// D(16x16) += A(16x4) * B(4x16), f32 in / f32 accumulate.
+// lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15];
+// it receives D[row = 4*(l>>4) + r][col = l&15] in element r of the accumulator.
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Exact-erf GELU (nn.GELU() default in the reference MLP, models/attention_model.py:21,27),
+// branch free.  erfc(a), a >= 0, by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7):
+//   erfc(a) = (a1 t + a2 t^2 + a3 t^3 + a4 t^4 + a5 t^5) exp(-a^2),  t = 1/(1 + p a)
+// Phi(x) = 0.5 erfc(-x/sqrt2);  gelu(x) = x Phi(x);  gelu'(x) = Phi(x) + x phi(x).
+struct GeluParts { float cdf; float e; };      // e = exp(-x^2/2)
+__device__ __forceinline__ GeluParts gelu_parts(float x) {
+    const float a = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * a * a);
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float half_erfc = 0.5f * poly * t * e;            // 0.5 * erfc(|x|/sqrt2)
+    GeluParts r;
+    r.cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
+    r.e = e;
+    return r;
+}
+__device__ __forceinline__ float gelu_f(float x) { return x * gelu_parts(x).cdf; }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const GeluParts g = gelu_parts(x);
+    return fmaf(x * 0.39894228040143267794f, g.e, g.cdf);
+}
+
+__device__ __forceinline__ float wave_sum16(float v) {   // sum over the 16 lanes sharing l>>4
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum64(float v) {
+    v = wave_sum16(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+}  // namespace nrm

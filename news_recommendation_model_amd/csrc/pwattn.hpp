@@ -1,0 +1,48 @@
+// Parameter blocks and host-side launchers shared by the pointwise-attention kernels and capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nrm {
+
+// ---- forward (pwattn_fwd.hip)
+struct FwdParams {
+    const float* t;      // [B*T, ldt]
+    const float* h;      // [B*H, ldh]
+    const float* u;      // [B*H, ldu]   (includes fc1 bias)
+    const float* v;      // [B*T, ldv]
+    const float* wp;     // packed, see pack_wp_kernel
+    const float* w2;     // [D]
+    const float* b2;     // [1]
+    float* z;            // [M, D] or nullptr
+    float* s;            // [M]
+    long M;              // B*T*H
+    int T, H, D;
+    int ldt, ldh, ldu, ldv;
+    int rows;            // padded row count of packed W_p  (= nchunks * NT * 16)
+    int kchunks;         // ceil(D/16)
+    int nchunks;         // number of N-chunks (each NT*16 output columns)
+};
+struct FwdPlan { int NT, MT, nchunks, rows, kchunks; };
+FwdPlan pwattn_fwd_plan(int D);
+hipError_t pwattn_fwd_launch(const FwdParams& p, const FwdPlan& pl, hipStream_t st);
+hipError_t pack_wp_launch(const float* w, int ldw, int D, const FwdPlan& pl, float* packed, hipStream_t st);
+
+// ---- backward (pwattn_bwd.hip)
+struct BwdEParams {
+    const float* X; long xs1, xs2, xrs;   // X_g[r,k] at X[g1*xs1 + g2*xs2 + r*xrs + k],  g = g1*G2 + g2
+    const float* Y; long ys1, yrs;        // Y_g[r,d] at Y[g1*ys1 + r*yrs + d]
+    const float* wp; int ldwp;            // W_p[k,d] at wp[k*ldwp + d]
+    const float* srow; int lds_;          // scale row of group g at srow[g*lds_ + d]     (WITH_DW)
+    float* out; int ldo;                  // out[g*ldo + d] += sum_k W_p[k,d] E_g[k,d]
+    float* ws;                            // [nsplit][D][D] partial dW_p, k-major             (WITH_DW)
+    int G, G2, R, D;
+    int gps;                              // groups per split
+    int nkw, ndcol;                       // k-ranges and d-columns of the wave-tile grid
+    long ntasks;                          // nkw * ndcol * nsplit wave tasks
+};
+struct BwdEPlan { int DT, KT, ndcol, nkw, nsplit, gps; };
+BwdEPlan bwd_e_plan(int D, int G, int target_waves);
+hipError_t bwd_e_launch(const BwdEParams& p, const BwdEPlan& pl, bool with_dw, hipStream_t st);
+hipError_t bwd_dz_launch(float* z, const float* ds, const float* w2, float* dw2, long M, int D, hipStream_t st);
+
+}  // namespace nrm

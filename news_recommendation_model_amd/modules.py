@@ -1,0 +1,188 @@
+"""nn.Module mirror of the reference model interface.
+
+Same class names, constructor arguments, forward signatures, reachable attributes and
+``state_dict`` keys as the reference's ``models/`` package, so its checkpoints load and its
+train/test drivers can call these classes unchanged:
+
+  MLP(input_dim, output_dim, activation_type='gelu')                 models/attention_model.py:10-32
+  PointwiseAttention(input_dim)                                      models/attention_model.py:34-44
+  PointwiseAttentionExpanded(input_dim)                              models/attention_model.py:47-97
+  UserInvariantInterestModel(embed_setting=[32,16,8,8])              models/user_invariant_interest_model.py:10-89
+  UserInstantInterestModel(output_dim)                               models/user_instant_interest_model.py:10-23
+  UserModel(user_num=0)  .forward(x_history, x_target, x_global), .loss(id, out, label, alpha)
+                                                                     models/user_model.py:12-43
+
+Modules can be built, pickled and (de)serialised on the CPU; ``forward`` needs an MI355X: the hot
+ops go through the C-ABI HIP kernels (ops.py) and raise on CPU tensors.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .config import Dims, TIME_TABLE_ROWS, model_config
+
+_ACTIVATIONS = {
+    "relu": nn.ReLU, "gelu": nn.GELU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid,
+    "leaky_relu": nn.LeakyReLU, "elu": nn.ELU,
+}
+
+
+class MLP(nn.Module):
+    """Linear(d, d//4) -> activation -> Linear(d//4, out); unknown activation names mean GELU."""
+
+    def __init__(self, input_dim, output_dim, activation_type="gelu"):
+        super().__init__()
+        self.fc1 = nn.Linear(input_dim, input_dim // 4)
+        self.fc2 = nn.Linear(input_dim // 4, output_dim)
+        self.activation_type = activation_type
+        self.activation = _ACTIVATIONS.get(str(activation_type).lower(), nn.GELU)()
+
+    def forward(self, x):
+        ops._require_gpu(x)
+        return self.fc2(self.activation(self.fc1(x)))
+
+
+def _scores(mlp: MLP, target, history):
+    if not isinstance(mlp.activation, nn.GELU):
+        raise RuntimeError("the HIP attention kernel implements the reference default (exact GELU) only")
+    return ops.pointwise_attention_scores(target, history, mlp.fc1.weight, mlp.fc1.bias,
+                                          mlp.fc2.weight, mlp.fc2.bias)
+
+
+class PointwiseAttentionExpanded(nn.Module):
+    """score[b,t,h] = MLP(cat[h, t, t-h, t*h]) for every (candidate, history) pair -> [B,T,H,1]."""
+
+    def __init__(self, input_dim):
+        super().__init__()
+        self.mlp = MLP(input_dim * 4, 1)
+
+    def forward(self, target, history):
+        if target.dim() == 2:                      # a single target per impression
+            target = target.unsqueeze(1)
+        return _scores(self.mlp, target, history).unsqueeze(-1)
+
+
+class PointwiseAttention(nn.Module):
+    """Non-broadcast variant (unused by UserModel): target and history have the same [N, D] shape,
+    one score per row.  Runs the same kernel with T = H = 1."""
+
+    def __init__(self, input_dim):
+        super().__init__()
+        self.mlp = MLP(input_dim * 4, 1)
+
+    def forward(self, target, history):
+        lead = target.shape[:-1]
+        d = target.shape[-1]
+        history = history.expand_as(target)
+        s = _scores(self.mlp, target.reshape(-1, 1, d), history.reshape(-1, 1, d))
+        return s.reshape(*lead, 1)
+
+
+class UserInvariantInterestModel(nn.Module):
+    """Embeds the packed history / candidate rows and pools the history with two pointwise
+    attentions (label features, text+image vector) -> (eu_H, ec)."""
+
+    def __init__(self, embed_setting=[32, 16, 8, 8]):
+        super().__init__()
+        self.embed_setting = embed_setting
+        dims = Dims.from_config(embed_setting, model_config)
+        self._dims = dims
+        e0, e1, e2, e3 = dims.embed_setting
+        # column widths of a packed row: time4 | text_img | category | sub-categories | sentiment | type | read | scroll
+        self.slice_len_list = [4, dims.pca_vector, 1, dims.n_subcat, dims.n_sentiment, 1, 1, 1]
+        self.category_embedding = nn.Sequential(nn.Embedding(dims.category_label_num, e0))
+        self.sentiment_embedding = nn.Sequential(nn.Linear(dims.n_sentiment, e1), nn.ReLU())
+        self.type_embedding = nn.Sequential(nn.Embedding(dims.n_type, e2))
+        self.w1 = nn.Linear(dims.label_dim + 2, dims.label_dim)
+        self.year_embedding = nn.Sequential(nn.Embedding(TIME_TABLE_ROWS[0], e3))
+        self.month_embedding = nn.Sequential(nn.Embedding(TIME_TABLE_ROWS[1], e3))
+        self.day_embedding = nn.Sequential(nn.Embedding(TIME_TABLE_ROWS[2], e3))
+        self.hour_embedding = nn.Sequential(nn.Embedding(TIME_TABLE_ROWS[3], e3))
+        self.label_attention = PointwiseAttentionExpanded(dims.label_dim)
+        self.text_img_attention = PointwiseAttentionExpanded(dims.pca_vector)
+
+    # -- helpers ---------------------------------------------------------------------------
+    def slice_x(self, x, n):
+        return list(torch.split(x[:, :, :sum(self.slice_len_list[:n])], self.slice_len_list[:n], dim=2))
+
+    def feature_embedding(self, category, sub_category, sentiment, type):
+        table = self.category_embedding[0].weight
+        cat = F.embedding(category[..., 0].long(), table)
+        sub = F.embedding(sub_category.long(), table).mean(dim=2)       # mean includes padding id 0
+        sen = self.sentiment_embedding(sentiment)
+        typ = F.embedding(type[..., 0].long(), self.type_embedding[0].weight)
+        return torch.cat((cat + sub, sen, typ), dim=2)
+
+    def time_embedding(self, time):
+        idx = time.long()
+        return (self.year_embedding[0](idx[..., 0]) + self.month_embedding[0](idx[..., 1])
+                + self.day_embedding[0](idx[..., 2]) + self.hour_embedding[0](idx[..., 3]))
+
+    def forward(self, x_history, x_target):
+        ops._require_gpu(x_history, x_target)
+        time_h, ti_h, cat_h, sub_h, sen_h, typ_h, read_h, scroll_h = self.slice_x(x_history.to(torch.float32), 8)
+        time_t, ti_t, cat_t, sub_t, sen_t, typ_t = self.slice_x(x_target.to(torch.float32), 6)
+
+        lab_h = torch.cat((self.feature_embedding(cat_h, sub_h, sen_h, typ_h), self.time_embedding(time_h),
+                           read_h, scroll_h), dim=2)
+        lab_h = self.w1(lab_h)
+        lab_t = torch.cat((self.feature_embedding(cat_t, sub_t, sen_t, typ_t), self.time_embedding(time_t)), dim=2)
+        ec = torch.cat((lab_t, ti_t), dim=2)
+
+        ti_h = ti_h.contiguous()
+        s_lab = self.label_attention(lab_t, lab_h)                     # [B,T,H,1]
+        s_ti = self.text_img_attention(ti_t, ti_h)
+        # un-normalised weighted pool: sum_h score * history  (no softmax, padding not masked)
+        pooled_lab = torch.bmm(s_lab.squeeze(-1), lab_h)
+        pooled_ti = torch.bmm(s_ti.squeeze(-1), ti_h)
+        return torch.cat((pooled_lab, pooled_ti), dim=2), ec
+
+
+class UserInstantInterestModel(nn.Module):
+    """ReLU(Linear(3 -> output_dim)) on the per-candidate popularity scalars."""
+
+    def __init__(self, output_dim):
+        super().__init__()
+        self.output_dim = output_dim
+        self.out_fc = nn.Sequential(nn.Linear(3, output_dim), nn.ReLU())
+
+    def forward(self, x_global):
+        ops._require_gpu(x_global)
+        return self.out_fc(x_global.to(torch.float32))
+
+
+class UserModel(nn.Module):
+    """cat[eu_H, eu_L, ec] -> BatchNorm gate -> MLP -> MLP -> one logit per candidate."""
+
+    def __init__(self, user_num=0):
+        super().__init__()
+        self.invariant_interest_model = UserInvariantInterestModel()
+        self.instant_interest_model = UserInstantInterestModel(8)
+        width = (sum(self.invariant_interest_model.embed_setting) + model_config["pca_vector"]) * 2 \
+            + self.instant_interest_model.output_dim
+        self.bn = nn.BatchNorm1d(width)
+        self.gate = MLP(width, width)
+        self.mlp = MLP(width, width)
+        self.out_mlp = MLP(width, 1)
+        self.delta = nn.Parameter(torch.zeros(user_num + 1))
+        self.bce_loss = nn.BCELoss()
+        self.softmax = nn.Softmax(dim=1)
+
+    def forward(self, x_history, x_target, x_global):
+        eu_H, ec = self.invariant_interest_model(x_history, x_target)
+        eu_L = self.instant_interest_model(x_global)
+        e = torch.cat((eu_H, eu_L, ec), dim=2)
+        B, T, N = e.shape
+        rows = e.reshape(B * T, N)
+        gated = self.gate(self.bn(rows)) * rows            # the gate multiplies the RAW concat
+        return self.out_mlp(self.mlp(gated)).reshape(B, T)
+
+    def loss(self, id, out, label, alpha=0.95):
+        y = label.to(torch.float32)
+        plain = self.bce_loss(self.softmax(out), y)
+        shifted = out + self.delta[id].unsqueeze(1)
+        personal = self.bce_loss(self.softmax(shifted), y)
+        return (1 - alpha) * plain + alpha * personal

@@ -1,0 +1,84 @@
+"""ctypes binding of libnrm_hotpath.so (C ABI: include/nrm_hotpath.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails, a RuntimeError is
+raised -- the product path never silently runs anything but the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnrm_hotpath.so")
+ABI_VERSION = 1
+
+_c_fp = ctypes.c_void_p      # device pointers travel as integers
+_c_i, _c_l = ctypes.c_int, ctypes.c_long
+
+# name -> (restype, argtypes); must list every symbol include/nrm_hotpath.h declares
+SIGNATURES = {
+    "nrm_abi_version": (_c_i, []),
+    "nrm_last_error": (ctypes.c_char_p, []),
+    "nrm_pwattn_packed_floats": (_c_l, [_c_i]),
+    "nrm_pwattn_pack_wp": (_c_i, [_c_fp, _c_i, _c_i, _c_fp, _c_fp]),
+    "nrm_pwattn_fwd": (_c_i, [_c_fp] * 9 + [_c_i] * 4 + [_c_fp]),
+    "nrm_pwattn_bwd_dz": (_c_i, [_c_fp] * 4 + [_c_l, _c_i, _c_fp]),
+    "nrm_pwattn_bwd_nsplit": (_c_i, [_c_i] * 4),
+    "nrm_pwattn_bwd_contract": (_c_i, [_c_fp] * 4 + [_c_i] + [_c_fp] * 3 + [_c_i] * 5 + [_c_fp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load (once) and return the ctypes library; raises RuntimeError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m news_recommendation_model_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback for the hot path.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        if lib.nrm_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"ABI mismatch: library {lib.nrm_abi_version()} != binding {ABI_VERSION}; rebuild")
+        _lib = lib
+    return _lib
+
+
+# Optional per-launch timing (bench.py): when a list is installed here every kernel-launching call is
+# bracketed by two events recorded on the stream the kernels are launched on (torch's current stream).
+kernel_events = None
+
+
+def call(name, *args, tag=None):
+    """Call an int-returning entry point; non-zero return raises with the library's message."""
+    lib = load()
+    if kernel_events is not None:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args)
+        e1.record()
+        kernel_events.append((tag or name, e0, e1))
+    else:
+        rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib.nrm_last_error().decode()}")
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,41 @@
+"""CPU: the C-ABI library loads and exports every symbol include/nrm_hotpath.h declares; the host-side
+argument validation works without a GPU (no compute call is made here)."""
+import os
+import re
+
+from conftest import ROOT
+from news_recommendation_model_amd import native
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "nrm_hotpath.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nrm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = header_functions()
+    assert len(names) >= 8
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in nrm_hotpath.h but not exported"
+        assert n in native.SIGNATURES, f"{n} has no ctypes signature in native.py"
+    assert sorted(native.SIGNATURES) == names
+
+
+def test_abi_version_and_sizes(lib):
+    assert lib.nrm_abi_version() == native.ABI_VERSION
+    for D in (64, 72, 256, 400, 768):
+        n16 = (D + 15) // 16
+        assert lib.nrm_pwattn_packed_floats(D) >= n16 * 16 * n16 * 16
+    assert lib.nrm_pwattn_bwd_nsplit(1024, 30, 50, 400) >= 1
+    assert lib.nrm_pwattn_bwd_nsplit(1, 1, 1, 64) == 1
+
+
+def test_host_validation_rejects_bad_shapes(lib):
+    # null pointers / bad D are refused on the host before any launch
+    rc = lib.nrm_pwattn_fwd(None, None, None, None, None, None, None, None, None, 2, 3, 4, 66, None)
+    assert rc != 0 and b"multiple of 4" in lib.nrm_last_error()
+    rc = lib.nrm_pwattn_fwd(None, None, None, None, None, None, None, None, None, 2, 3, 4, 64, None)
+    assert rc != 0 and b"null" in lib.nrm_last_error()
+    rc = lib.nrm_pwattn_bwd_contract(None, None, None, None, 256, None, None, None, 1 << 20, 64, 64, 64, 3, None)
+    assert rc != 0 and b"2^31" in lib.nrm_last_error()

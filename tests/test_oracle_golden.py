@@ -1,0 +1,66 @@
+"""CPU: the oracle (oracle/user_model_oracle.py) reproduces every golden fixture generated from the
+real reference (oracle/make_golden.py).  This is what keeps the oracle pinned on machines where the
+reference itself is absent (the GPU box)."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import MODEL_CASES, ZERO_GRAD_KEYS, load_case, pick, rel_err
+from oracle import user_model_oracle as orc
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_oracle_matches_fixture(name):
+    case, dims, batch, sd, fx = load_case(name)
+    tb = {k: torch.from_numpy(v) for k, v in batch.items() if isinstance(v, np.ndarray) and v.ndim > 0}
+    full = case["full"]
+    if case["mode"] == "eval":
+        p = orc.to_torch_params(sd, requires_grad=False)
+        with torch.no_grad():
+            r, aux = orc.user_model_forward(p, tb["x_history"], tb["x_target"], tb["x_global"], training=False,
+                                            return_aux=True)
+            loss = orc.user_model_loss(p, tb["user_id"], r, tb["label"])
+        assert rel_err(r.numpy(), fx["r"]) < 1e-5
+        assert abs(float(loss) - float(fx["loss"])) < 1e-6
+        assert rel_err(aux["eu_H"].numpy(), fx["eu_H"]) < 1e-5
+        return
+    p = orc.to_torch_params(sd)
+    opt_state = {"step": 0, "m": {}, "v": {}}
+    loss, r, grads = orc.train_step(p, opt_state, tb)
+    assert rel_err(r.numpy(), fx["r"]) < 1e-5
+    assert abs(float(loss) - float(fx["loss"])) < 1e-6
+    gscale = max(float(fx["gradnorm/" + k]) for k in grads)
+    for k, g in grads.items():
+        ref = fx["grad/" + k]
+        got = pick(g.numpy(), full)
+        if k in ZERO_GRAD_KEYS:
+            assert np.abs(got).max() < 1e-6 * max(1.0, gscale)
+        else:
+            assert np.abs(got - ref).max() <= 1e-2 * np.abs(ref).max() + 1e-9, k
+    # Adam: wherever |g| >> eps the first step moves a weight by ~lr*sign(g); compare absolutely
+    for k in p:
+        ref = fx["after/" + k]
+        got = pick(p[k].detach().numpy(), full)
+        assert np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() < 2.5e-3, k
+    np.testing.assert_allclose(orc.batch_auc(batch["label"], fx["r"]), fx["auc"], atol=1e-12)
+
+
+def test_oracle_attention_2d_target():
+    import os
+    from golden_util import GOLDEN
+    fx = np.load(os.path.join(GOLDEN, "attention_2d.npz"))
+    p = {"a." + k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("w/")}
+    s = orc.pointwise_attention_scores(p, "a", torch.from_numpy(fx["target"]), torch.from_numpy(fx["history"]))
+    assert tuple(s.shape) == tuple(fx["scores"].shape)
+    assert rel_err(s.numpy(), fx["scores"]) < 1e-5
+    pm = {"m." + k[6:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("mlp_w/")}
+    y = orc.mlp(pm, "m", torch.from_numpy(fx["mlp_x"]))
+    assert rel_err(y.numpy(), fx["mlp_y"]) < 1e-5
+
+
+def test_row_auc_ties_and_errors():
+    assert orc.row_auc([0, 1, 0], [0.1, 0.9, 0.3]) == 1.0
+    assert orc.row_auc([0, 1, 0], [0.5, 0.5, 0.5]) == 0.5
+    assert orc.row_auc([1, 0, 0, 0], [0.2, 0.2, 0.1, 0.9]) == pytest.approx((1 + 0.5) / 3)
+    with pytest.raises(ValueError):
+        orc.row_auc([0, 0], [0.1, 0.2])
