@@ -47,15 +47,41 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """CPUs this process may really use: the cgroup quota if there is one (the GPU box exposes 256 logical
+    CPUs but grants a 16-CPU share; 256 threads on 16 CPUs ran the oracle 50x slower), else the affinity."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    quota_found = False
+    for path, two in (("/sys/fs/cgroup/cpu.max", True), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", False)):
+        try:
+            txt = open(path).read().split()
+            if two:
+                quota, period = txt[0], txt[1]
+            else:
+                quota, period = txt[0], open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0]
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(int(quota) / int(period))))
+                quota_found = True
+                break
+        except Exception:
+            pass
+    if not quota_found and n > 32:
+        n = 16          # a 1-GPU box of this pool grants a 16-CPU share of its 256 logical CPUs
+    env = os.environ.get("NRM_CPU_THREADS")
+    if env:
+        n = int(env)
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(dims, wl, seconds, cpu_batch):
     """Oracle train step (reference-literal: materialises the [B,T,H,4D] concat) on the host cores."""
     from news_recommendation_model_amd import synth
     from oracle import user_model_oracle as orc
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
     # bounded sample: concat bytes = B*T*H*4D*4 per attention; keep it around 0.25 GB
     per_imp = wl["T"] * wl["H"] * 4 * wl["emb"] * 4

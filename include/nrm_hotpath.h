@@ -50,7 +50,8 @@ int nrm_pwattn_bwd_dz(float* z_inout, const float* ds, const float* w2, float* d
 int nrm_pwattn_bwd_nsplit(int B, int T, int H, int D);
 /* backward, step 2 (the bilinear term): given dz [B,T,H,D], t, h and W_p (row stride ldwp)
  *   dt[b,t,d] += sum_{h,k} dz W_p[k,d] h[b,h,d]      dh[b,h,d] += sum_{t,k} dz W_p[k,d] t[b,t,d]
- *   ws[i] (i < nsplit) = partial dW_p[k,d] = sum_{b,t,h} dz[b,t,h,k] t[b,t,d] h[b,h,d]  (sum the slabs)
+ *   ws[i][d][k] (i < nsplit) = partial of dW_p[k,d] = sum_{b,t,h} dz[b,t,h,k] t[b,t,d] h[b,h,d]
+ *                              (TRANSPOSED slabs: sum them over i, then transpose)
  * dt/dh are accumulated into (float atomics), ws is overwritten.
  * passes: bit 0 = the (b,t)-grouped launch (dt, ws), bit 1 = the (b,h)-grouped launch (dh); 3 = both. */
 int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, const float* wp, int ldwp,

@@ -34,11 +34,11 @@ struct BwdEParams {
     const float* wp; int ldwp;            // W_p[k,d] at wp[k*ldwp + d]
     const float* srow; int lds_;          // scale row of group g at srow[g*lds_ + d]     (WITH_DW)
     float* out; int ldo;                  // out[g*ldo + d] += sum_k W_p[k,d] E_g[k,d]
-    float* ws;                            // [nsplit][D][D] partial dW_p, k-major             (WITH_DW)
+    float* ws;                            // [nsplit][D][D] partial dW_p^T  (ws[s][d][k])      (WITH_DW)
     int G, G2, R, D;
     int gps;                              // groups per split
     int nkw, ndcol;                       // k-ranges and d-columns of the wave-tile grid
-    long ntasks;                          // nkw * ndcol * nsplit wave tasks
+    int nsplit;
 };
 struct BwdEPlan { int DT, KT, ndcol, nkw, nsplit, gps; };
 BwdEPlan bwd_e_plan(int D, int G, int target_waves);

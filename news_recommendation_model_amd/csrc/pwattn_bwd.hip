@@ -10,9 +10,9 @@
 //                          pass 1: X_g = dz[b,t,:,:] (r = h), Y_g = h[b]    -> dt[b,t,d] = sum_k W_p[k,d] E_g[k,d]
 //                                                                             dW_p[k,d] += E_g[k,d] * t[b,t,d]
 //                          pass 2: X_g = dz[b,:,h,:] (r = t), Y_g = t[b]    -> dh[b,h,d] = sum_k W_p[k,d] E_g[k,d]
-//      Both passes together are exactly the 2x-forward FLOPs of a GEMM backward, but every output row is
-//      produced by one workgroup (plain stores, no float atomics on [B,T,D]/[B,H,D]) and dW_p is
-//      accumulated in registers across the groups a wave walks (one partial slab per split, summed after).
+//      Both passes together are exactly the 2x-forward FLOPs of a GEMM backward; dW_p is accumulated in
+//      registers across the groups a wave walks (one partial slab per split, summed after), and an output
+//      row receives one contiguous float-atomic add per k-range (5 at D=400).
 //   du = sum_t dz, dv = sum_h dz and the side-projection gradients are plain reductions/GEMMs done by the
 //   caller.
 #include "common.hpp"
@@ -80,131 +80,145 @@ hipError_t bwd_dz_launch(float* z, const float* ds, const float* w2, float* dw2,
 
 // ---------------------------------------------------------------------------------------------
 // (2) grouped contraction E_g = X_g^T Y_g with fused epilogue.
-// MFMA orientation: row index i = d (A operand = Y), column index j = k (B operand = X), so that a lane
-// holds 4 consecutive d of one k: float4 loads of W_p[k, d..d+3], float4 stores of dW_p.
-// Every WAVE is an independent task (d-column, k-range, split): 4 tasks per 256-thread workgroup, no
-// workgroup barrier.  A wave owns a (DT*16 d) x (KT*16 k) tile of E/dW_p, walks the groups of its split,
-// and adds its k-partial of out[g, d-range] with float atomics shaped as contiguous segments
-// (ntasks_k adds per output element; `out` must be initialised by the caller).
+// MFMA orientation: row index i = k (A operand = X = dz), column index j = d (B operand = Y), so a lane
+// holds 4 consecutive k of one d: the k-reduction of out[g,d] = sum_k W_p[k,d] E_g[k,d] is in-lane plus two
+// cross-lane steps, W_p^T comes as float4 along k from an LDS tile, and dW_p is kept transposed ([d][k]).
 //
-// KS < KT splits the wave's k-range into two sub-passes per group ([0,KS) then [KS,KT)) so that only
-// DT*KS accumulator tiles of E are live beside the DT*KT tiles of dW_p (register budget: 2 waves/SIMD).
+// Work decomposition: the (KT*16 k) x (DT*16 d) wave tiles of E / dW_p form an nkw x ndcol grid; the G
+// groups are cut into `nsplit` splits.  A workgroup = 4 waves that share ONE wave tile (so its W_p^T tile
+// lives once in LDS) and take 4 consecutive splits; each wave walks the groups of its split on its own
+// (no workgroup barrier after the prologue).  A wave adds its k-partial of out[g, d-range] with float
+// atomics shaped as contiguous 256-B segments (nkw adds per output element; `out` is initialised by the
+// caller) and stores its dW_p^T partial as one slab per split.
+//
+// KS < DT splits the wave's d-range into two sub-passes per group ([0,KS) then [KS,DT)) so that only KT*KS
+// tiles of E are live beside the KT*DT tiles of dW_p (register budget for 2 waves/SIMD).
+// EXACT: D is a multiple of both tile widths -> no column masks / clamped offsets (fewer VGPRs and VALU).
 template <int N> struct IC { static constexpr int value = N; };
 
-template <int DT, int KT, int KS, bool WITH_DW>
+template <int KT, int DT, int KS, bool WITH_DW, bool EXACT>
 __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
-    static_assert(KS <= KT && KT - KS <= KS, "first sub-pass must be the larger one");
-    __shared__ __attribute__((aligned(16))) float bounce[4][DT * 16];    // wave-private, no barrier needed
+    static_assert(KS <= DT && DT - KS <= KS, "first sub-pass must be the larger one");
+    constexpr int LDK = KT * 16 + 4;                                   // padded row of the W_p^T tile
+    __shared__ __attribute__((aligned(16))) float smem[DT * 16 * LDK + 4 * DT * 16];
+    float* wpt = smem;                                                  // [DT*16 d][LDK]  = W_p[k0+k][d0+d]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    float* bounce = smem + DT * 16 * LDK + wave * (DT * 16);           // wave-private
     const int r16 = lane & 15, q = lane >> 4;
     const int D = p.D, R = p.R;
 
-    const long task = (long)blockIdx.x * 4 + wave;
-    if (task >= p.ntasks) return;
-    const int kw = (int)(task % p.nkw);
-    const int dcol = (int)((task / p.nkw) % p.ndcol);
-    const int split = (int)(task / ((long)p.nkw * p.ndcol));
+    const int tile = blockIdx.x;
+    const int kw = tile % p.nkw, dcol = tile / p.nkw;
     const int d0 = dcol * (DT * 16);
     const int k0 = kw * (KT * 16);
 
+    // ---- prologue: W_p^T tile -> LDS (zero padded), one barrier
+    for (int idx = tid; idx < KT * 16 * DT * 4; idx += 256) {
+        const int kl = idx / (DT * 4), d4 = idx - kl * (DT * 4);
+        const int k = k0 + kl, d = d0 + 4 * d4;
+        f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (k < D && d < D) w = *reinterpret_cast<const f32x4*>(p.wp + (long)k * p.ldwp + d);     // D % 4 == 0
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wpt[(4 * d4 + e) * LDK + kl] = w[e];
+    }
+    __syncthreads();
+
+    const int split = blockIdx.y * 4 + wave;
+    if (split >= p.nsplit) return;
     const int g_lo = split * p.gps;
     const int g_hi = min(p.G, g_lo + p.gps);
 
-    // per-lane operand columns; invalid columns read column 0 and are zeroed
-    // (loads are unconditional + AND-masked: a select would let hipcc sink each load into an exec-masked
-    //  branch followed by vmcnt(0), which serialises the operand prefetch)
-    int offA[DT], offB[KT];
-    unsigned mA[DT], mB[KT];
+    // per-lane operand columns.  General path: out-of-range columns read column 0 and are AND-masked by the
+    // consumer (a select on the load would be sunk into an exec-masked branch + vmcnt(0) by hipcc).
+    int offA[EXACT ? 1 : KT], offB[EXACT ? 1 : DT];
+    unsigned mA[EXACT ? 1 : KT], mB[EXACT ? 1 : DT];
+    if (!EXACT) {
 #pragma unroll
-    for (int it = 0; it < DT; ++it) { const int d = d0 + 16 * it + r16; mA[it] = d < D ? 0xffffffffu : 0u; offA[it] = d < D ? d : 0; }
+        for (int it = 0; it < KT; ++it) { const int k = k0 + 16 * it + r16; mA[it] = k < D ? 0xffffffffu : 0u; offA[it] = k < D ? k : 0; }
 #pragma unroll
-    for (int jt = 0; jt < KT; ++jt) { const int k = k0 + 16 * jt + r16; mB[jt] = k < D ? 0xffffffffu : 0u; offB[jt] = k < D ? k : 0; }
-
-    f32x4 dW[DT][KT];
-    if (WITH_DW) {
-#pragma unroll
-        for (int it = 0; it < DT; ++it)
-#pragma unroll
-            for (int jt = 0; jt < KT; ++jt) dW[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int jt = 0; jt < DT; ++jt) { const int d = d0 + 16 * jt + r16; mB[jt] = d < D ? 0xffffffffu : 0u; offB[jt] = d < D ? d : 0; }
     }
 
-    float an[DT], bn[KS];       // raw (unmasked) operands of the pending step
-    unsigned rmn = 0u;
-    // operands of reduction rows r0..r0+3 of group gg, k tiles [J0, J0+NJ)
+    f32x4 dW[KT][DT];
+    if (WITH_DW) {
+#pragma unroll
+        for (int it = 0; it < KT; ++it)
+#pragma unroll
+            for (int jt = 0; jt < DT; ++jt) dW[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    float an[KT], bn[KS];       // raw (unmasked) operands of the pending step
+    unsigned rmn = 0u;          // its row mask
+    // operands of reduction rows r0..r0+3 of group gg, d tiles [J0, J0+NJ)
     auto load_step = [&](auto j0c, auto njc, int gg, int r0) {
         constexpr int J0 = decltype(j0c)::value, NJ = decltype(njc)::value;
         const int g1 = gg / p.G2, g2 = gg - g1 * p.G2;
         const int r = r0 + q;
-        rmn = r < R ? 0xffffffffu : 0u;            // row mask of the pending step, applied by its consumer
+        rmn = r < R ? 0xffffffffu : 0u;
         const long rr = r < R ? r : 0;
-        const float* xp = p.X + (long)g1 * p.xs1 + (long)g2 * p.xs2 + rr * p.xrs;
-        const float* yp = p.Y + (long)g1 * p.ys1 + rr * p.yrs;
+        const float* xp = p.X + (long)g1 * p.xs1 + (long)g2 * p.xs2 + rr * p.xrs + (EXACT ? k0 + r16 : 0);
+        const float* yp = p.Y + (long)g1 * p.ys1 + rr * p.yrs + (EXACT ? d0 + r16 : 0);
 #pragma unroll
-        for (int it = 0; it < DT; ++it) an[it] = yp[offA[it]];
+        for (int it = 0; it < KT; ++it) an[it] = EXACT ? xp[16 * it] : xp[offA[it]];
 #pragma unroll
-        for (int jt = 0; jt < NJ; ++jt) bn[jt] = xp[offB[J0 + jt]];
+        for (int jt = 0; jt < NJ; ++jt) bn[jt] = EXACT ? yp[16 * (J0 + jt)] : yp[offB[J0 + jt]];
     };
 
-    // one sub-pass of group g over k tiles [J0, J0+NJ); prefetches the first step of the following
-    // sub-pass (tiles [NJ0, NJ0+NNJ) of group gn) under its last MFMAs.
-    auto sub_pass = [&](auto j0c, auto njc, auto nj0c, auto nnjc, int g, int gn, bool first_of_group) {
+    // one sub-pass of group g over d tiles [J0, J0+NJ); prefetches the first step of the following sub-pass
+    // (tiles [NJ0, NJ0+NNJ) of group gn) under its last MFMAs.
+    auto sub_pass = [&](auto j0c, auto njc, auto nj0c, auto nnjc, int g, int gn) {
         constexpr int J0 = decltype(j0c)::value, NJ = decltype(njc)::value;
-        f32x4 E[DT][NJ];
+        f32x4 E[KT][NJ];
 #pragma unroll
-        for (int it = 0; it < DT; ++it)
+        for (int it = 0; it < KT; ++it)
 #pragma unroll
             for (int jt = 0; jt < NJ; ++jt) E[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         for (int r0 = 0; r0 < R; r0 += 4) {
-            float a[DT], b[NJ];
+            float a[KT], b[NJ];
 #pragma unroll
-            for (int it = 0; it < DT; ++it) a[it] = __uint_as_float(__float_as_uint(an[it]) & (mA[it] & rmn));
+            for (int it = 0; it < KT; ++it) a[it] = __uint_as_float(__float_as_uint(an[it]) & (EXACT ? rmn : (mA[it] & rmn)));
 #pragma unroll
-            for (int jt = 0; jt < NJ; ++jt) b[jt] = __uint_as_float(__float_as_uint(bn[jt]) & (mB[J0 + jt] & rmn));
+            for (int jt = 0; jt < NJ; ++jt) b[jt] = __uint_as_float(__float_as_uint(bn[jt]) & (EXACT ? rmn : (mB[J0 + jt] & rmn)));
             if (r0 + 4 < R) load_step(j0c, njc, g, r0 + 4);
             else if (gn < g_hi) load_step(nj0c, nnjc, gn, 0);
 #pragma unroll
-            for (int it = 0; it < DT; ++it)
+            for (int it = 0; it < KT; ++it)
 #pragma unroll
                 for (int jt = 0; jt < NJ; ++jt) E[it][jt] = mfma16(a[it], b[jt], E[it][jt]);
         }
 
+        // epilogue: lane holds E[k = k0+16it+4q+e][d = d0+16jt+r16]
 #pragma unroll
-        for (int it = 0; it < DT; ++it) {
-            const int dbase = d0 + 16 * it + 4 * q;
-            int dd = dbase < D ? dbase : 0;              // D % 4 == 0
-            // opaque to the optimiser: otherwise the DT*KT 64-bit W_p tile addresses are hoisted out of the
-            // group loop and spilled (they are cheap to recompute: one mad + one 64-bit add)
-            asm volatile("" : "+v"(dd));
-            f32x4 sr = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (WITH_DW) sr = *reinterpret_cast<const f32x4*>(p.srow + (long)g * p.lds_ + dd);
-            f32x4 dto = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int jt = 0; jt < NJ; ++jt) {
-                // E is exactly 0 wherever k or d is out of range (zero operands), so clamped loads are safe
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(p.wp + (offB[J0 + jt] * p.ldwp + dd));
-                dto += w4 * E[it][jt];
-                if (WITH_DW) dW[it][J0 + jt] += E[it][jt] * sr;
+        for (int jt = 0; jt < NJ; ++jt) {
+            const int dl = 16 * (J0 + jt) + r16;
+            float sr = 0.f;
+            if (WITH_DW) {
+                const int d = d0 + dl;
+                sr = p.srow[(long)g * p.lds_ + (EXACT || d < D ? d : 0)];
             }
+            float acc = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dto[e] = wave_sum16(dto[e]);
-            if (r16 == 0) {
-                f32x4* bp = reinterpret_cast<f32x4*>(&bounce[wave][16 * it + 4 * q]);
-                *bp = first_of_group ? dto : (*bp + dto);
+            for (int it = 0; it < KT; ++it) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(&wpt[dl * LDK + 16 * it + 4 * q]);
+                const f32x4 e4 = E[it][jt];
+                acc = fmaf(w4[0], e4[0], fmaf(w4[1], e4[1], fmaf(w4[2], e4[2], fmaf(w4[3], e4[3], acc))));
+                if (WITH_DW) dW[it][J0 + jt] += e4 * sr;
             }
-            // keep hipcc from hoisting all DT*NJ W_p loads to the top of the epilogue (4 registers each)
-            __builtin_amdgcn_sched_barrier(0);
+            acc += __shfl_xor(acc, 16);
+            acc += __shfl_xor(acc, 32);
+            if (q == 0) bounce[dl] = acc;
         }
     };
 
     if (g_lo < g_hi) load_step(IC<0>{}, IC<KS>{}, g_lo, 0);
     for (int g = g_lo; g < g_hi; ++g) {
-        if constexpr (KS == KT) {
-            sub_pass(IC<0>{}, IC<KT>{}, IC<0>{}, IC<KT>{}, g, g + 1, true);
+        if constexpr (KS == DT) {
+            sub_pass(IC<0>{}, IC<DT>{}, IC<0>{}, IC<DT>{}, g, g + 1);
         } else {
-            sub_pass(IC<0>{}, IC<KS>{}, IC<KS>{}, IC<KT - KS>{}, g, g, true);
-            sub_pass(IC<KS>{}, IC<KT - KS>{}, IC<0>{}, IC<KS>{}, g, g + 1, false);
+            sub_pass(IC<0>{}, IC<KS>{}, IC<KS>{}, IC<DT - KS>{}, g, g);
+            sub_pass(IC<KS>{}, IC<DT - KS>{}, IC<0>{}, IC<KS>{}, g, g + 1);
         }
         // k-partial of out[g, d0 .. d0+DT*16): one dword per lane, contiguous segments.
         // bounce[] is wave-private: LDS ops of one wave complete in order, the fences only pin hipcc.
@@ -214,26 +228,25 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
 #pragma unroll
         for (int c = 0; c < DT * 16; c += 64) {
             const int dl = c + lane;
-            if (dl < DT * 16 && d0 + dl < D) atomicAdd(orow + dl, bounce[wave][dl]);
+            if (dl < DT * 16 && (EXACT || d0 + dl < D)) atomicAdd(orow + dl, bounce[dl]);
         }
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         __builtin_amdgcn_wave_barrier();
     }
 
-    if (WITH_DW) {
+    if (WITH_DW) {      // slab layout is TRANSPOSED: ws[split][d][k]
         float* wsp = p.ws + (long)split * D * D;
 #pragma unroll
-        for (int it = 0; it < DT; ++it) {
-            const int dbase = d0 + 16 * it + 4 * q;
+        for (int jt = 0; jt < DT; ++jt) {
+            const int d = d0 + 16 * jt + r16;
 #pragma unroll
-            for (int jt = 0; jt < KT; ++jt) {
-                const int k = k0 + 16 * jt + r16;
-                if (k < D && dbase < D) *reinterpret_cast<f32x4*>(wsp + (long)k * D + dbase) = dW[it][jt];
+            for (int it = 0; it < KT; ++it) {
+                const int k = k0 + 16 * it + 4 * q;
+                if (EXACT || (k < D && d < D)) *reinterpret_cast<f32x4*>(wsp + (long)d * D + k) = dW[it][jt];
             }
         }
     }
 }
-
 
 BwdEPlan bwd_e_plan(int D, int G, int target_waves) {
     const int n16 = (D + 15) / 16;
@@ -243,23 +256,29 @@ BwdEPlan bwd_e_plan(int D, int G, int target_waves) {
     pl.ndcol = (n16 + pl.DT - 1) / pl.DT;
     pl.nkw = (n16 + pl.KT - 1) / pl.KT;
     const int tiles = pl.ndcol * pl.nkw;
-    int ns = (target_waves + tiles - 1) / tiles;
-    if (ns < 1) ns = 1;
+    // exactly ONE round of wave tasks: tiles * nsplit <= target_waves, nsplit a multiple of 4 (4 splits per
+    // workgroup).  One task more than the machine holds would add a whole second round.
+    int ns = target_waves / tiles / 4 * 4;
+    if (ns < 4) ns = 4;
     if (ns > G) ns = G > 0 ? G : 1;
     pl.gps = (G + ns - 1) / ns;
     pl.nsplit = pl.gps > 0 ? (G + pl.gps - 1) / pl.gps : 1;
     return pl;
 }
 
-template <int DT, int KT>
+template <int KT, int DT>
 static hipError_t launch_e_t(BwdEParams p, const BwdEPlan& pl, bool with_dw, hipStream_t st) {
-    p.nkw = pl.nkw; p.ndcol = pl.ndcol; p.gps = pl.gps;
-    p.ntasks = (long)pl.nkw * pl.ndcol * pl.nsplit;
-    const long nblk = (p.ntasks + 3) / 4;
-    if (nblk > 0x7fffffffL) return hipErrorInvalidValue;
-    constexpr int KS_DW = (DT * KT > 16) ? (KT + 1) / 2 : KT;     // 5x5 with dW: sub-passes of 3 + 2 tiles
-    if (with_dw) hipLaunchKernelGGL((bwd_e_kernel<DT, KT, KS_DW, true>), dim3((unsigned)nblk), dim3(256), 0, st, p);
-    else         hipLaunchKernelGGL((bwd_e_kernel<DT, KT, KT, false>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+    p.nkw = pl.nkw; p.ndcol = pl.ndcol; p.gps = pl.gps; p.nsplit = pl.nsplit;
+    const dim3 grid(pl.nkw * pl.ndcol, (pl.nsplit + 3) / 4), block(256);
+    const bool exact = p.D % (16 * KT) == 0 && p.D % (16 * DT) == 0;
+    constexpr int KS_DW = (DT * KT > 16) ? (DT + 1) / 2 : DT;     // 5x5 with dW: sub-passes of 3 + 2 d-tiles
+    if (with_dw) {
+        if (exact) hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, true>), grid, block, 0, st, p);
+        else       hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, false>), grid, block, 0, st, p);
+    } else {
+        if (exact) hipLaunchKernelGGL((bwd_e_kernel<KT, DT, DT, false, true>), grid, block, 0, st, p);
+        else       hipLaunchKernelGGL((bwd_e_kernel<KT, DT, DT, false, false>), grid, block, 0, st, p);
+    }
     return hipGetLastError();
 }
 

@@ -89,7 +89,7 @@ class _PointwiseAttentionScores(torch.autograd.Function):
             native.call("nrm_pwattn_bwd_contract", native.ptr(dz), native.ptr(t), native.ptr(h),
                         native.ptr(wp), 4 * D, native.ptr(dt), native.ptr(dh), native.ptr(ws), B, T, H, D,
                         passes, st, tag=tag)
-        dwp = ws.sum(dim=0)
+        dwp = ws.sum(dim=0).t()                             # slabs hold dW_p^T ([d][k])
         dw1 = torch.cat([da_h, da_t, da_t - da_h, dwp], dim=1)
         return dt, dh, dw1, db1, dw2.reshape(ctx.w2_shape), db2
 

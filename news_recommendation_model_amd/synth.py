@@ -130,7 +130,7 @@ def make_state_dict(dims: Dims, seed: int = 1, user_num: int | None = None, pert
             bound = 1.0 / np.sqrt(int(kind[2:]))
             a = rng.uniform(-bound, bound, shape)
         elif kind == "one":
-            a = 1.0 + (0.1 * rng.standard_normal(shape) if perturb else 0.0)
+            a = np.ones(shape) + (0.1 * rng.standard_normal(shape) if perturb else 0.0)
             if key.endswith("running_var"):
                 a = np.abs(a) + 0.05
         elif kind == "zero":
