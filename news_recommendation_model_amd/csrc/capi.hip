@@ -27,8 +27,9 @@ static int check_dims(const char* fn, int B, int T, int H, int D) {
     if (D % 4) return fail(NRM_EINVAL, "%s: D=%d must be a multiple of 4", fn, D);
     if (D > 1024) return fail(NRM_EINVAL, "%s: D=%d > 1024 not supported", fn, D);
     const long M = (long)B * T * H;
-    if (M >= (1L << 31) / 1 || (long)B * T * D >= (1L << 31) || (long)B * H * D >= (1L << 31))
-        return fail(NRM_EINVAL, "%s: B*T*H=%ld (or a [B,T,D]/[B,H,D] operand) exceeds 2^31 elements", fn, M);
+    // buffer descriptors address with 32-bit byte offsets; 2^31 is reserved as the "masked row" marker
+    if (M >= (1L << 31) || (long)B * T * D >= (1L << 29) || (long)B * H * D >= (1L << 29))
+        return fail(NRM_EINVAL, "%s: B*T*H=%ld exceeds 2^31 rows or a [B,T,D]/[B,H,D] operand exceeds 2^31 bytes", fn, M);
     return NRM_OK;
 }
 
@@ -61,6 +62,9 @@ int nrm_pwattn_fwd(const float* t, const float* h, const float* u, const float* 
     p.t = t; p.h = h; p.u = u; p.v = v; p.wp = packed_wp; p.w2 = w2; p.b2 = b2; p.z = z; p.s = s;
     p.M = (long)B * T * H; p.T = T; p.H = H; p.D = D;
     p.ldt = D; p.ldh = D; p.ldu = D; p.ldv = D;
+    p.wp_bytes = (unsigned)(nrm_pwattn_packed_floats(D) * 4);
+    p.t_bytes = (unsigned)((long)B * T * D * 4);
+    p.h_bytes = (unsigned)((long)B * H * D * 4);
     p.rows = pl.rows; p.kchunks = pl.kchunks; p.nchunks = pl.nchunks;
     return check_hip(nrm::pwattn_fwd_launch(p, pl, (hipStream_t)stream), "pwattn_fwd");
 }

@@ -7,6 +7,7 @@
 namespace nrm {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 constexpr int WAVE = 64;
 

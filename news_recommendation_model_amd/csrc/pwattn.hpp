@@ -18,6 +18,7 @@ struct FwdParams {
     long M;              // B*T*H
     int T, H, D;
     int ldt, ldh, ldu, ldv;
+    unsigned wp_bytes, t_bytes, h_bytes;   // buffer-descriptor extents (t/v share t_bytes, h/u share h_bytes)
     int rows;            // padded row count of packed W_p  (= nchunks * NT * 16)
     int kchunks;         // ceil(D/16)
     int nchunks;         // number of N-chunks (each NT*16 output columns)

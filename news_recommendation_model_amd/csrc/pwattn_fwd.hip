@@ -22,7 +22,9 @@ namespace nrm {
 
 // ---------------------------------------------------------------------------------------------
 // W_p prepack: packed[c][row][16] = W_p[row][16c .. 16c+15], zero padded to `rows` rows and to a
-// multiple of 16 columns, so that one K-chunk of one N-chunk is a single contiguous block.
+// multiple of 16 columns, so that one K-chunk of one N-chunk is a single contiguous block that LDS-DMA
+// copies verbatim.  Inside a 64-B row the four 16-B slots are XOR-swizzled (slot s holds columns
+// 4*(s ^ ((row>>2)&3)) ..+3): the unpadded LDS image is then read conflict-free with ds_read_b128.
 // W_p = fc1.weight[:, 3D:4D] (row stride ldw = 4D).
 __global__ void pack_wp_kernel(const float* __restrict__ w, int ldw, int D, int rows, int kchunks,
                                float* __restrict__ packed) {
@@ -32,43 +34,73 @@ __global__ void pack_wp_kernel(const float* __restrict__ w, int ldw, int D, int 
         const long rc = i >> 4;
         const int row = (int)(rc % rows);
         const int c = (int)(rc / rows);
-        const int d = c * 16 + j;
+        const int slot = (j >> 2) ^ ((row >> 2) & 3);
+        const int d = c * 16 + 4 * slot + (j & 3);
         packed[i] = (row < D && d < D) ? w[(long)row * ldw + d] : 0.0f;
     }
 }
 
 template <int NT, int MT, bool SAVE_Z>
 __global__ __launch_bounds__(256, 2) void pwattn_fwd_kernel(const FwdParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)      // buffer-descriptor types/builtins exist in the device pass only;
+                                         // without the guard the host pass silently drops the kernel stub
     constexpr int BM = 4 * MT * 16;       // data rows per workgroup
-    constexpr int LDW = 20;               // LDS row stride in floats (16 + 4 pad, keeps 16-B alignment)
     constexpr int WROWS = NT * 16;
-    constexpr int WF4 = WROWS * 4;        // float4 items of one W chunk
-    constexpr int WPT = (WF4 + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float smem[(WROWS + BM) * LDW];
-    float* Ws = smem;
-    float* Ps = smem + WROWS * LDW;
+    // one LDS buffer = [W chunk | t rows | h rows], every row 16 floats (64 B), unpadded (LDS-DMA image)
+    constexpr int BUF = (WROWS + 2 * BM) * 16;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];       // double buffered
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, q = lane >> 4;
     const int M = (int)p.M;                       // host guarantees M < 2^31
     const int m0 = blockIdx.x * BM;
     const int T = p.T, H = p.H, D = p.D;
 
-    // --- P staging assignment: MT float4 items per thread, item = tid + 256*j -> (row, c4 = tid&3).
-    // Out-of-range rows read row 0 (always valid) and are zeroed when the product is written.
-    const int c4 = tid & 3;
-    int t_off[MT], h_off[MT];
+    // All global traffic goes through buffer descriptors: 32-bit lane offsets (no 64-bit pointers to keep
+    // live or spill) and hardware bounds checking -- an offset >= num_records reads 0 / drops the store,
+    // which is how out-of-range rows (m >= M) are masked.
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, p.wp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.t), 0, p.t_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.h), 0, p.h_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.h_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v), 0, p.t_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w2), 0, D * 4, 0x00020000);
+    const int rows_here = min(BM, M - m0);
+    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(
+        SAVE_Z ? p.z + (size_t)m0 * D : nullptr, 0, SAVE_Z ? rows_here * D * 4 : 0, 0x00020000);
+
+    // --- staging (LDS-DMA): a wave copies its OWN MT*16 t rows and h rows (one 1-KiB piece = 16 rows x 64 B
+    // per wave-instruction, lane -> row lane>>2, 16-B slot lane&3) and every 4th 1-KiB piece of the W chunk.
+    // The source slot is XOR-swizzled with (row>>2)&3; readers apply the same XOR.
+    unsigned voff_t[MT], voff_h[MT];
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
-        const int m = m0 + ((tid + 256 * j) >> 2);
+        const int rl = lane >> 2;
+        const int m = m0 + (wave * MT + j) * 16 + rl;
         const unsigned mm = m < M ? (unsigned)m : 0u;
         const unsigned bt = mm / (unsigned)H;
         const unsigned b = bt / (unsigned)T;
         const unsigned hr = b * H + (mm - bt * H);
-        t_off[j] = (int)(bt * p.ldt);
-        h_off[j] = (int)(hr * p.ldh);
+        const unsigned slot = (unsigned)((lane & 3) ^ ((rl >> 2) & 3));
+        voff_t[j] = m < M ? (bt * p.ldt + 4 * slot) * 4u : OOB;
+        voff_h[j] = m < M ? (hr * p.ldh + 4 * slot) * 4u : OOB;
     }
+    // --- epilogue rows of this lane
+    unsigned voff_u[MT], voff_v[MT];
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt) {
+        const int m = m0 + (wave * MT + jt) * 16 + r16;
+        const unsigned mm = m < M ? (unsigned)m : 0u;
+        const unsigned bt = mm / (unsigned)H;
+        const unsigned b = bt / (unsigned)T;
+        const unsigned hr = b * H + (mm - bt * H);
+        voff_u[jt] = m < M ? (hr * p.ldu + 4 * q) * 4u : OOB;
+        voff_v[jt] = m < M ? (bt * p.ldv + 4 * q) * 4u : OOB;
+    }
+    const int rslot = 4 * (q ^ ((r16 >> 2) & 3));          // swizzled float offset of this lane's fragment slot
 
     float s_part[MT];
 #pragma unroll
@@ -76,76 +108,54 @@ __global__ __launch_bounds__(256, 2) void pwattn_fwd_kernel(const FwdParams p) {
 
     for (int nc = 0; nc < p.nchunks; ++nc) {
         // accumulators start at u[b,h,k] + v[b,t,k]: the loads land straight in the accumulator
-        // registers, so the epilogue needs no u/v traffic and no extra live registers.
+        // registers, so the epilogue needs no u/v traffic.
         const int kc0 = nc * WROWS;
         f32x4 acc[NT][MT];
 #pragma unroll
         for (int jt = 0; jt < MT; ++jt) {
-            const int m = m0 + (wave * MT + jt) * 16 + r16;
-            const unsigned mm = m < M ? (unsigned)m : 0u;
-            const unsigned bt = mm / (unsigned)H;
-            const unsigned b = bt / (unsigned)T;
-            const unsigned hr = b * H + (mm - bt * H);
-            const float* up = p.u + (size_t)hr * p.ldu;
-            const float* vp = p.v + (size_t)bt * p.ldv;
 #pragma unroll
             for (int it = 0; it < NT; ++it) {
-                const int k = kc0 + it * 16 + 4 * q;
-                const int kk = k < D ? k : 0;
-                const f32x4 uv = *reinterpret_cast<const f32x4*>(up + kk) + *reinterpret_cast<const f32x4*>(vp + kk);
-                acc[it][jt] = k < D ? uv : f32x4{0.f, 0.f, 0.f, 0.f};
+                const int kb = (kc0 + it * 16) * 4;                       // uniform byte offset of the tile
+                const f32x4 uu = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, voff_u[jt], kb, 0));
+                const f32x4 vv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, voff_v[jt], kb, 0));
+                const bool kok = kc0 + it * 16 + 4 * q < D;               // only matters when D % 16 != 0
+                acc[it][jt] = kok ? uu + vv : f32x4{0.f, 0.f, 0.f, 0.f};
+                // bound the burst (8 loads in flight): all 2*NT*MT at once would be the register peak of
+                // the kernel and push values used in the K loop into scratch
+                if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
 
-        f32x4 wreg[WPT], treg[MT], hreg[MT];
-        bool dok = true;
-        auto load_chunk = [&](int c) {
-            // the packed buffer is over-allocated by 256 float4, so the tail items may over-read
-            const f32x4* src = reinterpret_cast<const f32x4*>(p.wp + ((long)c * p.rows + (long)nc * WROWS) * 16);
-#pragma unroll
-            for (int j = 0; j < WPT; ++j) wreg[j] = src[tid + 256 * j];
-            int dcol = c * 16 + 4 * c4;
-            dok = dcol < D;                 // D % 4 == 0 -> a float4 is entirely valid or entirely out
-            dcol = dok ? dcol : 0;
+        // K-chunk c of this N-chunk -> LDS buffer `buf` (asynchronous; completion is tracked by vmcnt).
+        // Columns >= D of the last chunk need no mask: the packed W_p is zero there.
+        auto dma_chunk = [&](int c, float* buf) {
+            const int wbase = (c * p.rows + nc * WROWS) * 64;             // bytes, uniform
+            for (int pc = wave; pc < NT; pc += 4)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(buf + pc * 256),
+                                                         16, lane * 16, wbase + pc * 1024, 0, 0);
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
-                treg[j] = *reinterpret_cast<const f32x4*>(p.t + t_off[j] + dcol);
-                hreg[j] = *reinterpret_cast<const f32x4*>(p.h + h_off[j] + dcol);
+                float* tdst = buf + (WROWS + (wave * MT + j) * 16) * 16;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_t, (__attribute__((address_space(3))) void*)tdst, 16, voff_t[j], c * 64, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (__attribute__((address_space(3))) void*)(tdst + BM * 16), 16, voff_h[j], c * 64, 0, 0);
             }
         };
-        auto store_chunk = [&]() {
+        auto compute = [&](const float* buf) {
+            const float* Tl = buf + WROWS * 16;
+            f32x4 pf[MT];                                    // B operand rows: P[m,:] = t[b,t,:] * h[b,h,:]
 #pragma unroll
-            for (int j = 0; j < WPT; ++j) {
-                const int idx = tid + 256 * j;
-                if (idx < WF4) *reinterpret_cast<f32x4*>(&Ws[(idx >> 2) * LDW + 4 * (idx & 3)]) = wreg[j];
+            for (int jt = 0; jt < MT; ++jt) {
+                const int ro = ((wave * MT + jt) * 16 + r16) * 16 + rslot;
+                pf[jt] = *reinterpret_cast<const f32x4*>(&Tl[ro]) * *reinterpret_cast<const f32x4*>(&Tl[BM * 16 + ro]);
             }
-#pragma unroll
-            for (int j = 0; j < MT; ++j) {
-                const int row = (tid + 256 * j) >> 2;
-                const bool ok = dok && (m0 + row < M);
-                const f32x4 pr = treg[j] * hreg[j];
-                *reinterpret_cast<f32x4*>(&Ps[row * LDW + 4 * c4]) = ok ? pr : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        };
-
-        load_chunk(0);
-        for (int c = 0; c < p.kchunks; ++c) {
-            __syncthreads();                 // every wave is done reading the previous chunk
-            store_chunk();
-            __syncthreads();
-            if (c + 1 < p.kchunks) load_chunk(c + 1);   // global loads fly under the MFMAs below
-
-            f32x4 pf[MT];
-#pragma unroll
-            for (int jt = 0; jt < MT; ++jt)
-                pf[jt] = *reinterpret_cast<const f32x4*>(&Ps[((wave * MT + jt) * 16 + r16) * LDW + 4 * q]);
             // W fragments are read one tile ahead; the scheduling barrier keeps hipcc from hoisting
-            // all NT reads in front of the MFMAs (that costs 4*NT registers and spills).
-            f32x4 af = *reinterpret_cast<const f32x4*>(&Ws[r16 * LDW + 4 * q]);
+            // all NT reads in front of the MFMAs (that costs 4*NT registers).
+            f32x4 af = *reinterpret_cast<const f32x4*>(&buf[r16 * 16 + rslot]);
 #pragma unroll
             for (int it = 0; it < NT; ++it) {
                 f32x4 afn = af;
-                if (it + 1 < NT) afn = *reinterpret_cast<const f32x4*>(&Ws[((it + 1) * 16 + r16) * LDW + 4 * q]);
+                if (it + 1 < NT) afn = *reinterpret_cast<const f32x4*>(&buf[((it + 1) * 16 + r16) * 16 + rslot]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -153,28 +163,34 @@ __global__ __launch_bounds__(256, 2) void pwattn_fwd_kernel(const FwdParams p) {
                 __builtin_amdgcn_sched_barrier(0);
                 af = afn;
             }
+        };
+
+        // pipeline: DMA of chunk c+1 flies under the MFMAs of chunk c; one barrier per chunk
+        // (__syncthreads() waits for this wave's DMA -- vmcnt(0) -- before the barrier).
+        dma_chunk(0, smem);
+        __syncthreads();
+        for (int c = 0; c < p.kchunks; ++c) {
+            float* cur = smem + (c & 1) * BUF;
+            float* nxt = smem + ((c & 1) ^ 1) * BUF;
+            if (c + 1 < p.kchunks) dma_chunk(c + 1, nxt);
+            compute(cur);
+            __syncthreads();
         }
 
         // --- epilogue of this N-chunk: optional z store ; GELU ; partial fc2 dot
-        float* zp[MT];
-        bool mok[MT];
-#pragma unroll
-        for (int jt = 0; jt < MT; ++jt) {
-            const int m = m0 + (wave * MT + jt) * 16 + r16;
-            mok[jt] = m < M;
-            zp[jt] = SAVE_Z ? p.z + (size_t)(mok[jt] ? m : 0) * D : nullptr;
-        }
 #pragma unroll
         for (int it = 0; it < NT; ++it) {
-            const int k = kc0 + it * 16 + 4 * q;
-            if (k < D) {
-                const f32x4 ww = *reinterpret_cast<const f32x4*>(p.w2 + k);
+            const int kb = (kc0 + it * 16) * 4;
+            const bool kok = kc0 + it * 16 + 4 * q < D;
+            const f32x4 ww = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, 16 * q, kb, 0));   // 0 beyond D
 #pragma unroll
-                for (int jt = 0; jt < MT; ++jt) {
-                    const f32x4 zz = acc[it][jt];
-                    if (SAVE_Z && mok[jt]) *reinterpret_cast<f32x4*>(zp[jt] + k) = zz;
-                    s_part[jt] += ww[0] * gelu_f(zz[0]) + ww[1] * gelu_f(zz[1]) + ww[2] * gelu_f(zz[2]) + ww[3] * gelu_f(zz[3]);
+            for (int jt = 0; jt < MT; ++jt) {
+                const f32x4 zz = acc[it][jt];
+                if (SAVE_Z && kok) {
+                    const unsigned vz = (unsigned)(((wave * MT + jt) * 16 + r16) * D + 4 * q) * 4u;   // rows >= M: out of range
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zz), rs_z, vz, kb, 0);
                 }
+                s_part[jt] += ww[0] * gelu_f(zz[0]) + ww[1] * gelu_f(zz[1]) + ww[2] * gelu_f(zz[2]) + ww[3] * gelu_f(zz[3]);
             }
         }
     }
@@ -188,6 +204,7 @@ __global__ __launch_bounds__(256, 2) void pwattn_fwd_kernel(const FwdParams p) {
         const int m = m0 + (wave * MT + jt) * 16 + r16;
         if (q == 0 && m < M) p.s[m] = v + b2;
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -196,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void pwattn_fwd_kernel(const FwdParams p) {
 // Tile table: NT 16-column tiles per N-chunk x MT 16-row tiles per wave.  4*NT*MT accumulator
 // registers must leave room for the staging prefetch at 2 waves/SIMD (<= 256 VGPRs, no scratch).
 static const int kNT[8] = {4, 6, 8, 10, 12, 13, 14, 16};
-static const int kMT[8] = {6, 5, 4, 3, 3, 3, 2, 2};
+static const int kMT[8] = {4, 4, 3, 3, 3, 3, 2, 2};     // also bounded by LDS: 2 workgroups x 2 buffers <= 160 KB
 
 FwdPlan pwattn_fwd_plan(int D) {
     const int n16 = (D + 15) / 16;
@@ -223,9 +240,9 @@ static hipError_t launch_fwd_t(const FwdParams& p, hipStream_t st) {
 
 hipError_t pwattn_fwd_launch(const FwdParams& p, const FwdPlan& pl, hipStream_t st) {
     switch (pl.NT) {
-        case 4:  return launch_fwd_t<4, 6>(p, st);
-        case 6:  return launch_fwd_t<6, 5>(p, st);
-        case 8:  return launch_fwd_t<8, 4>(p, st);
+        case 4:  return launch_fwd_t<4, 4>(p, st);
+        case 6:  return launch_fwd_t<6, 4>(p, st);
+        case 8:  return launch_fwd_t<8, 3>(p, st);
         case 10: return launch_fwd_t<10, 3>(p, st);
         case 12: return launch_fwd_t<12, 3>(p, st);
         case 13: return launch_fwd_t<13, 3>(p, st);
