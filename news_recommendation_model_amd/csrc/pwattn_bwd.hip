@@ -98,12 +98,14 @@ template <int N> struct IC { static constexpr int value = N; };
 
 template <int KT, int DT, int KS, bool WITH_DW, bool EXACT>
 __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)      // buffer-descriptor builtins: device pass only (keeps the host stub)
     static_assert(KS <= DT && DT - KS <= KS, "first sub-pass must be the larger one");
     constexpr int LDK = KT * 16 + 4;                                   // padded row of the W_p^T tile
     __shared__ __attribute__((aligned(16))) float smem[DT * 16 * LDK + 4 * DT * 16];
     float* wpt = smem;                                                  // [DT*16 d][LDK]  = W_p[k0+k][d0+d]
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably uniform -> SGPR math below
     float* bounce = smem + DT * 16 * LDK + wave * (DT * 16);           // wave-private
     const int r16 = lane & 15, q = lane >> 4;
     const int D = p.D, R = p.R;
@@ -128,16 +130,24 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
     if (split >= p.nsplit) return;
     const int g_lo = split * p.gps;
     const int g_hi = min(p.G, g_lo + p.gps);
+    const int nsteps = (R + 3) >> 2;
 
-    // per-lane operand columns.  General path: out-of-range columns read column 0 and are AND-masked by the
-    // consumer (a select on the load would be sunk into an exec-masked branch + vmcnt(0) by hipcc).
-    int offA[EXACT ? 1 : KT], offB[EXACT ? 1 : DT];
+    // Operands stream from global memory straight into MFMA operand registers through buffer descriptors
+    // rebuilt per group (uniform base = the group's first row, extent = R rows): the per-lane part of the
+    // address is ONE loop-invariant 32-bit offset (row q of the step, column of the lane), the step advances
+    // the scalar offset, and rows >= R read as 0 by the hardware bounds check -- no masks, no address VALU.
+    // General (non-EXACT) shapes also mask the columns >= D of the last tile.
+    const unsigned vx = (unsigned)((long)q * p.xrs + k0 + r16) * 4u;
+    const unsigned vy = (unsigned)((long)q * p.yrs + d0 + r16) * 4u;
+    const unsigned xbytes = (unsigned)(((long)(R - 1) * p.xrs + D) * 4);
+    const unsigned ybytes = (unsigned)(((long)(R - 1) * p.yrs + D) * 4);
+    const int xstep = (int)(p.xrs * 16), ystep = (int)(p.yrs * 16);     // 4 rows, bytes
     unsigned mA[EXACT ? 1 : KT], mB[EXACT ? 1 : DT];
     if (!EXACT) {
 #pragma unroll
-        for (int it = 0; it < KT; ++it) { const int k = k0 + 16 * it + r16; mA[it] = k < D ? 0xffffffffu : 0u; offA[it] = k < D ? k : 0; }
+        for (int it = 0; it < KT; ++it) mA[it] = k0 + 16 * it + r16 < D ? 0xffffffffu : 0u;
 #pragma unroll
-        for (int jt = 0; jt < DT; ++jt) { const int d = d0 + 16 * jt + r16; mB[jt] = d < D ? 0xffffffffu : 0u; offB[jt] = d < D ? d : 0; }
+        for (int jt = 0; jt < DT; ++jt) mB[jt] = d0 + 16 * jt + r16 < D ? 0xffffffffu : 0u;
     }
 
     f32x4 dW[KT][DT];
@@ -148,26 +158,33 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
             for (int jt = 0; jt < DT; ++jt) dW[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    float an[KT], bn[KS];       // raw (unmasked) operands of the pending step
-    unsigned rmn = 0u;          // its row mask
-    // operands of reduction rows r0..r0+3 of group gg, d tiles [J0, J0+NJ)
-    auto load_step = [&](auto j0c, auto njc, int gg, int r0) {
-        constexpr int J0 = decltype(j0c)::value, NJ = decltype(njc)::value;
+    // two operand register sets (ping-pong, no copies)
+    float a0[KT], b0[KS], a1[KT], b1[KS];
+    __amdgpu_buffer_rsrc_t rx, ry;
+    auto open_group = [&](int gg) {
         const int g1 = gg / p.G2, g2 = gg - g1 * p.G2;
-        const int r = r0 + q;
-        rmn = r < R ? 0xffffffffu : 0u;
-        const long rr = r < R ? r : 0;
-        const float* xp = p.X + (long)g1 * p.xs1 + (long)g2 * p.xs2 + rr * p.xrs + (EXACT ? k0 + r16 : 0);
-        const float* yp = p.Y + (long)g1 * p.ys1 + rr * p.yrs + (EXACT ? d0 + r16 : 0);
+        rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X + (long)g1 * p.xs1 + (long)g2 * p.xs2), 0, xbytes, 0x00020000);
+        ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Y + (long)g1 * p.ys1), 0, ybytes, 0x00020000);
+    };
+    // operands of reduction step s (rows 4s..4s+3) of the open group, d tiles [J0, J0+NJ)
+    auto load_step = [&](auto j0c, auto njc, float (&a)[KT], float (&b)[KS], int s) {
+        constexpr int J0 = decltype(j0c)::value, NJ = decltype(njc)::value;
 #pragma unroll
-        for (int it = 0; it < KT; ++it) an[it] = EXACT ? xp[16 * it] : xp[offA[it]];
+        for (int it = 0; it < KT; ++it) {
+            const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rx, vx + 64 * it, s * xstep, 0);
+            a[it] = __uint_as_float(EXACT ? v : (v & mA[it]));
+        }
 #pragma unroll
-        for (int jt = 0; jt < NJ; ++jt) bn[jt] = EXACT ? yp[16 * (J0 + jt)] : yp[offB[J0 + jt]];
+        for (int jt = 0; jt < NJ; ++jt) {
+            const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(ry, vy + 64 * (J0 + jt), s * ystep, 0);
+            b[jt] = __uint_as_float(EXACT ? v : (v & mB[J0 + jt]));
+        }
     };
 
-    // one sub-pass of group g over d tiles [J0, J0+NJ); prefetches the first step of the following sub-pass
-    // (tiles [NJ0, NJ0+NNJ) of group gn) under its last MFMAs.
-    auto sub_pass = [&](auto j0c, auto njc, auto nj0c, auto nnjc, int g, int gn) {
+    // one sub-pass of group g over d tiles [J0, J0+NJ).  On entry set 0 holds step 0.  After its last MFMA
+    // batch it prefetches step 0 of the following sub-pass (tiles [NJ0, NJ0+NNJ) of group gn) into set 0,
+    // so that latency hides under the epilogue.
+    auto sub_pass = [&](auto j0c, auto njc, auto nj0c, auto nnjc, int g, int gn, bool first_of_group) {
         constexpr int J0 = decltype(j0c)::value, NJ = decltype(njc)::value;
         f32x4 E[KT][NJ];
 #pragma unroll
@@ -175,18 +192,23 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
 #pragma unroll
             for (int jt = 0; jt < NJ; ++jt) E[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        for (int r0 = 0; r0 < R; r0 += 4) {
-            float a[KT], b[NJ];
-#pragma unroll
-            for (int it = 0; it < KT; ++it) a[it] = __uint_as_float(__float_as_uint(an[it]) & (EXACT ? rmn : (mA[it] & rmn)));
-#pragma unroll
-            for (int jt = 0; jt < NJ; ++jt) b[jt] = __uint_as_float(__float_as_uint(bn[jt]) & (EXACT ? rmn : (mB[J0 + jt] & rmn)));
-            if (r0 + 4 < R) load_step(j0c, njc, g, r0 + 4);
-            else if (gn < g_hi) load_step(nj0c, nnjc, gn, 0);
+        auto mfma_batch = [&](const float (&a)[KT], const float (&b)[KS]) {
 #pragma unroll
             for (int it = 0; it < KT; ++it)
 #pragma unroll
                 for (int jt = 0; jt < NJ; ++jt) E[it][jt] = mfma16(a[it], b[jt], E[it][jt]);
+        };
+        for (int s = 0; s < nsteps; s += 2) {
+            if (s + 1 < nsteps) load_step(j0c, njc, a1, b1, s + 1);
+            mfma_batch(a0, b0);
+            if (s + 1 < nsteps) {
+                if (s + 2 < nsteps) load_step(j0c, njc, a0, b0, s + 2);
+                mfma_batch(a1, b1);
+            }
+        }
+        if (gn < g_hi) {
+            if (gn != g) open_group(gn);
+            load_step(nj0c, nnjc, a0, b0, 0);
         }
 
         // epilogue: lane holds E[k = k0+16it+4q+e][d = d0+16jt+r16]
@@ -210,15 +232,19 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
             acc += __shfl_xor(acc, 32);
             if (q == 0) bounce[dl] = acc;
         }
+        (void)first_of_group;
     };
 
-    if (g_lo < g_hi) load_step(IC<0>{}, IC<KS>{}, g_lo, 0);
+    if (g_lo < g_hi) {
+        open_group(g_lo);
+        load_step(IC<0>{}, IC<KS>{}, a0, b0, 0);
+    }
     for (int g = g_lo; g < g_hi; ++g) {
         if constexpr (KS == DT) {
-            sub_pass(IC<0>{}, IC<DT>{}, IC<0>{}, IC<DT>{}, g, g + 1);
+            sub_pass(IC<0>{}, IC<DT>{}, IC<0>{}, IC<DT>{}, g, g + 1, true);
         } else {
-            sub_pass(IC<0>{}, IC<KS>{}, IC<KS>{}, IC<DT - KS>{}, g, g);
-            sub_pass(IC<KS>{}, IC<DT - KS>{}, IC<0>{}, IC<KS>{}, g, g + 1);
+            sub_pass(IC<0>{}, IC<KS>{}, IC<KS>{}, IC<DT - KS>{}, g, g, true);
+            sub_pass(IC<KS>{}, IC<DT - KS>{}, IC<0>{}, IC<KS>{}, g, g + 1, false);
         }
         // k-partial of out[g, d0 .. d0+DT*16): one dword per lane, contiguous segments.
         // bounce[] is wave-private: LDS ops of one wave complete in order, the fences only pin hipcc.
@@ -246,6 +272,7 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
             }
         }
     }
+#endif
 }
 
 BwdEPlan bwd_e_plan(int D, int G, int target_waves) {
