@@ -106,7 +106,8 @@ int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, con
         p.Y = t; p.ys1 = TD; p.yrs = D;
         p.wp = wp; p.ldwp = ldwp; p.srow = nullptr; p.lds_ = 0; p.out = dh; p.ldo = D; p.ws = nullptr;
         p.G = B * H; p.G2 = H; p.R = T; p.D = D;
-        const nrm::BwdEPlan pl = nrm::bwd_e_plan(D, p.G, kTargetWaves);
+        // this variant keeps no dW_p accumulators (<= 168 VGPRs): three waves per SIMD
+        const nrm::BwdEPlan pl = nrm::bwd_e_plan(D, p.G, kTargetWaves * 3 / 2);
         if (int rc = check_hip(nrm::bwd_e_launch(p, pl, false, (hipStream_t)stream), "bwd_e pass 2")) return rc;
     }
     return NRM_OK;

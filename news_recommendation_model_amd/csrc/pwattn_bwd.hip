@@ -110,8 +110,17 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
     const int r16 = lane & 15, q = lane >> 4;
     const int D = p.D, R = p.R;
 
-    const int tile = blockIdx.x;
-    const int kw = tile % p.nkw, dcol = tile / p.nkw;
+    // XCD-aware block order.  The ndcol tiles that share one (split group, k-range) read the SAME dz bytes:
+    // give them consecutive logical ids and map consecutive logical ids to one XCD (hardware deals linear
+    // block ids round-robin over the 8 XCDs, each with its own L2), so that four of the five reads of a dz
+    // line are L2 hits instead of HBM/fabric fetches.  Pure speed: any mapping is correct.
+    const int nblk = gridDim.x * gridDim.y;
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = lin & 7;         // bijective for any nblk
+    const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+    const int dcol = logical % p.ndcol;
+    const int kw = (logical / p.ndcol) % p.nkw;
+    const int sgrp = logical / (p.ndcol * p.nkw);
     const int d0 = dcol * (DT * 16);
     const int k0 = kw * (KT * 16);
 
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
     }
     __syncthreads();
 
-    const int split = blockIdx.y * 4 + wave;
+    const int split = sgrp * 4 + wave;
     if (split >= p.nsplit) return;
     const int g_lo = split * p.gps;
     const int g_hi = min(p.G, g_lo + p.gps);
