@@ -42,10 +42,12 @@ int nrm_pwattn_fwd(const float* t, const float* h, const float* u, const float* 
                    const float* w2, const float* b2, float* z, float* s,
                    int B, int T, int H, int D, nrm_stream_t stream);
 
-/* backward, step 1 (autograd of attention_model.py:29-32 through GELU and fc2):
- *   z <- dz = ds * w2 * gelu'(z) in place;  dw2[k] += sum ds*gelu(z)   (dw2 must be initialised) */
-int nrm_pwattn_bwd_dz(float* z_inout, const float* ds, const float* w2, float* dw2,
-                      long M, int D, nrm_stream_t stream);
+/* backward, step 1 (autograd of attention_model.py:29-32 through GELU and fc2), one pass over z:
+ *   z <- dz = ds * w2 * gelu'(z) in place;  dw2[k] += sum ds*gelu(z)   (dw2 must be initialised)
+ *   du[b,h,:] = sum_t dz[b,t,h,:]  (gradient of u)      dv[b,t,:] = sum_h dz[b,t,h,:]  (gradient of v)
+ * ds [B,T,H]; du [B,H,D] and dv [B,T,D] are overwritten.  H <= 300. */
+int nrm_pwattn_bwd_dz(float* z_inout, const float* ds, const float* w2, float* dw2, float* du, float* dv,
+                      int B, int T, int H, int D, nrm_stream_t stream);
 /* number of [D,D] partial slabs nrm_pwattn_bwd_contract writes into `ws` */
 int nrm_pwattn_bwd_nsplit(int B, int T, int H, int D);
 /* backward, step 2 (the bilinear term): given dz [B,T,H,D], t, h and W_p (row stride ldwp)
@@ -57,6 +59,39 @@ int nrm_pwattn_bwd_nsplit(int B, int T, int H, int D);
 int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, const float* wp, int ldwp,
                             float* dt, float* dh, float* ws,
                             int B, int T, int H, int D, int passes, nrm_stream_t stream);
+
+/* ---- dense layers: reference MLP.forward (models/attention_model.py:29-32: fc1 -> GELU -> fc2), the history
+ *      projection w1 (models/user_invariant_interest_model.py:78) and the attention's side projections.
+ * Weights are re-packed per call into the kernel's streaming layout (they change every optimizer step).
+ * All activation matrices are row-major with a leading dimension that is a multiple of 4 floats and 16-byte
+ * aligned rows; padding columns [ncols, ld) must hold finite values (the library writes zeros there).       */
+#define NRM_EPI_BIAS 0   /* y = x W^T + bias                                                              */
+#define NRM_EPI_GELU 1   /* z = x W^T + bias (saved for backward), y = gelu(z)                            */
+#define NRM_EPI_DGELU 2  /* y = (x W^T) * gelu'(z)      (z = pre-activation saved by NRM_EPI_GELU)        */
+long nrm_gemm_packed_floats(int nrows, int ncols);
+/* packs the logical [nrows x ncols] matrix src[r*row_stride + c*col_stride]; rows become output columns of
+ * nrm_gemm_nt, columns its reduction index.  Linear.forward: (W[N,K], K, 1, N, K); dX = dY W: (W, 1, K, K, N) */
+int nrm_gemm_pack(const float* src, long row_stride, long col_stride, int nrows, int ncols, float* packed,
+                  nrm_stream_t stream);
+/* y[M, N] (ld ldy) = epilogue( x[M, K] (ld ldx) * packed^T ), bias [N] or NULL */
+int nrm_gemm_nt(const float* x, int ldx, int M, const float* packed, int N, int K, const float* bias,
+                float* y, int ldy, float* z, int ldz, int epilogue, nrm_stream_t stream);
+/* C[i,j] = sum_r A[r,i] B[r,j]  (dW = dY^T X): writes nsplit TRANSPOSED partial slabs ws[s][j][ldws] and, if
+ * colsum != NULL, colsum[s][i] = sum_r A[r,i] (the bias gradient); sum over s.  ldws % 4 == 0, ldws >= ncols_i */
+int nrm_gemm_tn_nsplit(int ncols_i, int ncols_j, int R);
+int nrm_gemm_tn(const float* A, int lda, int ncols_i, const float* B, int ldb, int ncols_j, int R,
+                float* ws, int ldws, float* colsum, nrm_stream_t stream);
+
+/* ---- BatchNorm1d over rows (reference models/user_model.py:18,32), N % 4 == 0, ld % 4 == 0.
+ * nrm_colreduce mode 0: s0 += sum_r x;  1: s0 += sum_r (x-mean)^2;  2: s0 += sum_r dy, s1 += sum_r dy*(x-mean)*rstd */
+int nrm_colreduce(int mode, const float* x, const float* dy, const float* mean, const float* rstd,
+                  float* s0, float* s1, int R, int N, int ld, nrm_stream_t stream);
+int nrm_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                 float* y, int R, int N, int ld, nrm_stream_t stream);
+/* training != 0: dx = gamma*rstd*(dy - s0/R - xhat*s1/R) with s0,s1 from nrm_colreduce mode 2; else gamma*rstd*dy */
+int nrm_bn_backward(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                    const float* s0, const float* s1, float* dx, int R, int N, int ld, int training,
+                    nrm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,9 +1,12 @@
 // extern "C" entry points declared in include/nrm_hotpath.h: host-side validation + launches only.
 #include <stdarg.h>
+#include <stdint.h>
 #include <stdio.h>
 
 #include "../../include/nrm_hotpath.h"
 #include "pwattn.hpp"
+#include "gemm.hpp"
+#include "head.hpp"
 
 static thread_local char g_err[512] = "";
 
@@ -69,10 +72,12 @@ int nrm_pwattn_fwd(const float* t, const float* h, const float* u, const float* 
     return check_hip(nrm::pwattn_fwd_launch(p, pl, (hipStream_t)stream), "pwattn_fwd");
 }
 
-int nrm_pwattn_bwd_dz(float* z_inout, const float* ds, const float* w2, float* dw2, long M, int D, nrm_stream_t stream) {
-    if (!z_inout || !ds || !w2 || !dw2) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dz: null pointer");
-    if (M < 0 || D <= 0 || D % 4 || D > 1024) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dz: M=%ld D=%d", M, D);
-    return check_hip(nrm::bwd_dz_launch(z_inout, ds, w2, dw2, M, D, (hipStream_t)stream), "bwd_dz");
+int nrm_pwattn_bwd_dz(float* z_inout, const float* ds, const float* w2, float* dw2, float* du, float* dv,
+                      int B, int T, int H, int D, nrm_stream_t stream) {
+    if (int rc = check_dims("nrm_pwattn_bwd_dz", B, T, H, D)) return rc;
+    if (!z_inout || !ds || !w2 || !dw2 || !du || !dv) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dz: null pointer");
+    if (H > 300) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dz: H=%d > 300 (the du slab must fit the 160 KB LDS)", H);
+    return check_hip(nrm::bwd_dz_launch(z_inout, ds, w2, dw2, du, dv, B, T, H, D, (hipStream_t)stream), "bwd_dz");
 }
 
 int nrm_pwattn_bwd_nsplit(int B, int T, int H, int D) {
@@ -111,6 +116,92 @@ int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, con
         if (int rc = check_hip(nrm::bwd_e_launch(p, pl, false, (hipStream_t)stream), "bwd_e pass 2")) return rc;
     }
     return NRM_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------- dense layers
+static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+long nrm_gemm_packed_floats(int nrows, int ncols) {
+    if (nrows <= 0 || ncols <= 0) return 0;
+    const nrm::GemmNtPlan pl = nrm::gemm_nt_plan(nrows);
+    return (long)((ncols + 15) / 16) * pl.rows * 16 + 1024;
+}
+
+int nrm_gemm_pack(const float* src, long row_stride, long col_stride, int nrows, int ncols, float* packed,
+                  nrm_stream_t stream) {
+    if (!src || !packed || nrows <= 0 || ncols <= 0) return fail(NRM_EINVAL, "nrm_gemm_pack: bad argument");
+    const nrm::GemmNtPlan pl = nrm::gemm_nt_plan(nrows);
+    return check_hip(nrm::pack_rows_launch(src, row_stride, col_stride, nrows, ncols, pl.rows, (ncols + 15) / 16, packed,
+                                           (hipStream_t)stream), "pack_rows");
+}
+
+int nrm_gemm_nt(const float* x, int ldx, int M, const float* packed, int N, int K, const float* bias,
+                float* y, int ldy, float* z, int ldz, int epilogue, nrm_stream_t stream) {
+    if (!x || !packed || !y) return fail(NRM_EINVAL, "nrm_gemm_nt: null pointer");
+    if (M < 0 || N <= 0 || K <= 0) return fail(NRM_EINVAL, "nrm_gemm_nt: M=%d N=%d K=%d", M, N, K);
+    if (ldx % 4 || ldy % 4 || ldx < K || ldy < N || !al16(x) || !al16(y))
+        return fail(NRM_EINVAL, "nrm_gemm_nt: ldx=%d ldy=%d must be multiples of 4 covering K=%d / N=%d, rows 16-B aligned", ldx, ldy, K, N);
+    if (epilogue != NRM_EPI_BIAS && (!z || ldz % 4 || ldz < N || !al16(z)))
+        return fail(NRM_EINVAL, "nrm_gemm_nt: epilogue %d needs z with ldz %% 4 == 0, ldz >= N", epilogue);
+    if (epilogue < 0 || epilogue > 2) return fail(NRM_EINVAL, "nrm_gemm_nt: epilogue=%d", epilogue);
+    if ((long)256 * (ldx > ldy ? ldx : ldy) * 4 >= (1L << 31)) return fail(NRM_EINVAL, "nrm_gemm_nt: leading dimension too large");
+    const nrm::GemmNtPlan pl = nrm::gemm_nt_plan(N);
+    nrm::GemmNtParams p;
+    p.x = x; p.ldx = ldx; p.xcols = ldx; p.wp = packed; p.wp_bytes = (unsigned)(nrm_gemm_packed_floats(N, K) * 4);
+    p.rows = pl.rows; p.bias = bias; p.N = N; p.y = y; p.ldy = ldy;
+    p.z = epilogue == NRM_EPI_BIAS ? nullptr : z; p.ldz = epilogue == NRM_EPI_BIAS ? 4 : ldz;
+    p.M = M; p.kchunks = (K + 15) / 16;
+    return check_hip(nrm::gemm_nt_launch(p, pl, epilogue, (hipStream_t)stream), "gemm_nt");
+}
+
+int nrm_gemm_tn_nsplit(int ncols_i, int ncols_j, int R) {
+    if (ncols_i <= 0 || ncols_j <= 0 || R <= 0) return 0;
+    return nrm::gemm_tn_plan(ncols_i, ncols_j, R, kTargetWaves).nsplit;
+}
+
+int nrm_gemm_tn(const float* A, int lda, int ncols_i, const float* B, int ldb, int ncols_j, int R,
+                float* ws, int ldws, float* colsum, nrm_stream_t stream) {
+    if (!A || !B || !ws) return fail(NRM_EINVAL, "nrm_gemm_tn: null pointer");
+    if (ncols_i <= 0 || ncols_j <= 0 || R <= 0 || lda < ncols_i || ldb < ncols_j)
+        return fail(NRM_EINVAL, "nrm_gemm_tn: ncols_i=%d ncols_j=%d R=%d lda=%d ldb=%d", ncols_i, ncols_j, R, lda, ldb);
+    if (ldws % 4 || ldws < ncols_i || !al16(ws)) return fail(NRM_EINVAL, "nrm_gemm_tn: ldws=%d", ldws);
+    const nrm::GemmTnPlan pl = nrm::gemm_tn_plan(ncols_i, ncols_j, R, kTargetWaves);
+    if ((long)pl.rps * (lda > ldb ? lda : ldb) * 4 >= (1L << 31)) return fail(NRM_EINVAL, "nrm_gemm_tn: split too large");
+    nrm::GemmTnParams p = {};
+    p.A = A; p.lda = lda; p.acols = lda; p.B = B; p.ldb = ldb; p.bcols = ldb;
+    p.ws = ws; p.ldws = ldws; p.colsum = colsum; p.R = R; p.ncols_j = ncols_j;
+    return check_hip(nrm::gemm_tn_launch(p, pl, (hipStream_t)stream), "gemm_tn");
+}
+
+// ------------------------------------------------------------------------------------------- BatchNorm
+static int check_bn(const char* fn, int R, int N, int ld) {
+    if (R < 0 || N <= 0 || N % 4 || ld % 4 || ld < N) return fail(NRM_EINVAL, "%s: R=%d N=%d ld=%d (N, ld multiples of 4)", fn, R, N, ld);
+    return NRM_OK;
+}
+
+int nrm_colreduce(int mode, const float* x, const float* dy, const float* mean, const float* rstd,
+                  float* s0, float* s1, int R, int N, int ld, nrm_stream_t stream) {
+    if (int rc = check_bn("nrm_colreduce", R, N, ld)) return rc;
+    if (!x || !s0 || (mode >= 1 && !mean) || (mode == 2 && (!dy || !rstd || !s1)) || mode < 0 || mode > 2)
+        return fail(NRM_EINVAL, "nrm_colreduce: bad argument for mode %d", mode);
+    return check_hip(nrm::colred_launch(mode, x, dy, mean, rstd, s0, s1, R, N, ld, (hipStream_t)stream), "colreduce");
+}
+
+int nrm_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                 float* y, int R, int N, int ld, nrm_stream_t stream) {
+    if (int rc = check_bn("nrm_bn_apply", R, N, ld)) return rc;
+    if (!x || !mean || !rstd || !gamma || !beta || !y) return fail(NRM_EINVAL, "nrm_bn_apply: null pointer");
+    return check_hip(nrm::bn_apply_launch(x, mean, rstd, gamma, beta, y, R, N, ld, (hipStream_t)stream), "bn_apply");
+}
+
+int nrm_bn_backward(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                    const float* s0, const float* s1, float* dx, int R, int N, int ld, int training,
+                    nrm_stream_t stream) {
+    if (int rc = check_bn("nrm_bn_backward", R, N, ld)) return rc;
+    if (!dy || !rstd || !gamma || !dx || (training && (!x || !mean || !s0 || !s1)))
+        return fail(NRM_EINVAL, "nrm_bn_backward: null pointer");
+    return check_hip(nrm::bn_bwd_launch(x, dy, mean, rstd, gamma, s0, s1, dx, R, N, ld, training, (hipStream_t)stream), "bn_backward");
 }
 
 }  // extern "C"

@@ -1,0 +1,315 @@
+// fp32 MFMA GEMMs for the dense layers of the hot path (reference models/attention_model.py:29-32 MLP,
+// models/user_invariant_interest_model.py:33,78 w1, the side projections of the attention).  gfx950 only.
+//
+//   gemm_nt   Y[M,N] = epi( X[M,K] * W^T )      W given as "packed rows" (pack_rows_kernel), X row-major.
+//             Used for Linear.forward (rows of W = output features) and for dX = dY * W (rows = input
+//             features, packed from W with swapped strides).  Same skeleton as pwattn_fwd_kernel: LDS-DMA
+//             staging of a [rows x 16] weight chunk + the workgroup's X rows, double buffered, one barrier per
+//             K-chunk; MFMA rows = output columns so a lane owns 4 consecutive outputs of one row (float4 I/O).
+//             Epilogues: bias | bias+GELU (stores pre-activation and activation) | *gelu'(saved pre-activation).
+//   gemm_tn   C[N,K] = sum_m A[m,N]^T B[m,K]     (dW = dY^T X, plus db = column sums of dY).
+//             Reduction runs over the ROW index of both operands, so operands stream straight from global
+//             memory into MFMA operand registers (one dword per lane per tile, ping-pong prefetch), the row
+//             range is split over waves and every wave stores one partial slab (transposed: [K][N]).
+#include "common.hpp"
+#include "gemm.hpp"
+
+namespace nrm {
+
+// packed[c][row][16]: element (row, 16c + 4*(s ^ ((row>>2)&3)) + e) of the logical [nrows x ncols] matrix
+// src[row*rs + col*cs], zero padded to `rows` rows / 16*kchunks columns (slot swizzle: see pwattn_fwd.hip).
+__global__ void pack_rows_kernel(const float* __restrict__ src, long rs, long cs, int nrows, int ncols,
+                                 int rows, int kchunks, float* __restrict__ packed) {
+    const long total = (long)kchunks * rows * 16;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 15);
+        const long rc = i >> 4;
+        const int row = (int)(rc % rows);
+        const int c = (int)(rc / rows);
+        const int slot = (j >> 2) ^ ((row >> 2) & 3);
+        const int col = c * 16 + 4 * slot + (j & 3);
+        packed[i] = (row < nrows && col < ncols) ? src[row * rs + col * cs] : 0.0f;
+    }
+}
+
+hipError_t pack_rows_launch(const float* src, long rs, long cs, int nrows, int ncols, int rows, int kchunks,
+                            float* packed, hipStream_t st) {
+    const long total = (long)kchunks * rows * 16;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, st, src, rs, cs, nrows, ncols, rows, kchunks, packed);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int NT, int MT, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNtParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 4 * MT * 16;
+    constexpr int WROWS = NT * 16;
+    constexpr int BUF = (WROWS + BM) * 16;                           // [W chunk | X rows], 16 floats per row
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int M = p.M;
+    const int m0 = blockIdx.x * BM;
+    const int nc = blockIdx.y;                                       // N-chunk of this workgroup
+    const int n0 = nc * WROWS;
+
+    constexpr unsigned OOB = 0x80000000u;
+    const int rows_here = min(BM, M - m0);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, p.wp_bytes, 0x00020000);
+    // per-workgroup descriptors: base = first row of the block, extent = its valid rows -> rows >= M read 0 /
+    // are not stored, and every offset fits 32 bits whatever M is
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x) + (size_t)m0 * p.ldx, 0, ((rows_here - 1) * p.ldx + p.xcols) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)m0 * p.ldy, 0, rows_here * p.ldy * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(
+        p.z ? p.z + (size_t)m0 * p.ldz : nullptr, 0, p.z ? rows_here * p.ldz * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? (p.N + 3) / 4 * 16 : 0, 0x00020000);
+
+    unsigned voff_x[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int rl = (wave * MT + j) * 16 + (lane >> 2);
+        const unsigned slot = (unsigned)((lane & 3) ^ (((lane >> 2) >> 2) & 3));
+        voff_x[j] = rl < rows_here ? (unsigned)(rl * p.ldx + 4 * slot) * 4u : OOB;
+    }
+    const int rslot = 4 * (q ^ ((r16 >> 2) & 3));
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < MT; ++jt) acc[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Columns >= K of the last chunk are multiplied by the zero padding of the packed weights; what X holds
+    // there only has to be finite (caller guarantee: row padding up to ldx is zero-initialised).
+    auto dma_chunk = [&](int c, float* buf) {
+        const int wbase = (c * p.rows + n0) * 64;
+        for (int pc = wave; pc < NT; pc += 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(buf + pc * 256),
+                                                     16, lane * 16, wbase + pc * 1024, 0, 0);
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(buf + (WROWS + (wave * MT + j) * 16) * 16),
+                                                     16, voff_x[j], c * 64, 0, 0);
+    };
+    auto compute = [&](const float* buf) {
+        const float* Xl = buf + WROWS * 16;
+        f32x4 pf[MT];
+#pragma unroll
+        for (int jt = 0; jt < MT; ++jt) pf[jt] = *reinterpret_cast<const f32x4*>(&Xl[((wave * MT + jt) * 16 + r16) * 16 + rslot]);
+        f32x4 af = *reinterpret_cast<const f32x4*>(&buf[r16 * 16 + rslot]);
+#pragma unroll
+        for (int it = 0; it < NT; ++it) {
+            f32x4 afn = af;
+            if (it + 1 < NT) afn = *reinterpret_cast<const f32x4*>(&buf[((it + 1) * 16 + r16) * 16 + rslot]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int jt = 0; jt < MT; ++jt) acc[it][jt] = mfma16(af[j], pf[jt][j], acc[it][jt]);
+            __builtin_amdgcn_sched_barrier(0);
+            af = afn;
+        }
+    };
+
+    dma_chunk(0, smem);
+    __syncthreads();
+    for (int c = 0; c < p.kchunks; ++c) {
+        float* cur = smem + (c & 1) * BUF;
+        float* nxt = smem + ((c & 1) ^ 1) * BUF;
+        if (c + 1 < p.kchunks) dma_chunk(c + 1, nxt);
+        compute(cur);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds out[m = m0 + (wave*MT+jt)*16 + r16][n = n0 + 16 it + 4q .. +3]
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+        const int n = n0 + it * 16 + 4 * q;
+        const int nb = (n0 + it * 16) * 4;
+        f32x4 bb = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EPI != EPI_DGELU && p.bias) {
+            // the descriptor extent is rounded up to 16 B (a float4 must not straddle it); lanes past N are zeroed
+            bb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, 16 * q, nb, 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bb[e] = n + e < p.N ? bb[e] : 0.f;
+        }
+#pragma unroll
+        for (int jt = 0; jt < MT; ++jt) {
+            const int rl = (wave * MT + jt) * 16 + r16;
+            f32x4 v = acc[it][jt] + bb;
+            if (EPI == EPI_BIAS) {
+                if (n < p.ldy) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb, 0);
+            } else if (EPI == EPI_GELU) {
+                if (n < p.ldz) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_z, (unsigned)(rl * p.ldz + 4 * q) * 4u, nb, 0);
+                f32x4 g;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = gelu_f(v[e]);
+                if (n < p.ldy) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb, 0);
+            } else {   // EPI_DGELU: y = acc * gelu'(z_saved)
+                f32x4 zz = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (n < p.ldz) zz = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_z, (unsigned)(rl * p.ldz + 4 * q) * 4u, nb, 0));
+                f32x4 g;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = acc[it][jt][e] * gelu_grad_f(zz[e]);
+                if (n < p.ldy) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+}
+
+GemmNtPlan gemm_nt_plan(int N) {
+    const int n16 = (N + 15) / 16;
+    GemmNtPlan pl;
+    if (n16 <= 4) { pl.NT = 4; pl.MT = 4; }
+    else {
+        // 13x2 (exact for N = 402/416, 3 % padding for 1608) or 8x3, whichever pads less
+        const int p13 = (n16 + 12) / 13 * 13, p8 = (n16 + 7) / 8 * 8;
+        if (p13 <= p8) { pl.NT = 13; pl.MT = 2; } else { pl.NT = 8; pl.MT = 3; }
+    }
+    pl.nchunks = (n16 + pl.NT - 1) / pl.NT;
+    pl.rows = pl.nchunks * pl.NT * 16;
+    return pl;
+}
+
+template <int NT, int MT>
+static hipError_t launch_nt(const GemmNtParams& p, const GemmNtPlan& pl, int epi, hipStream_t st) {
+    constexpr int BM = 4 * MT * 16;
+    const dim3 grid((p.M + BM - 1) / BM, pl.nchunks), block(256);
+    switch (epi) {
+        case EPI_BIAS:  hipLaunchKernelGGL((gemm_nt_kernel<NT, MT, EPI_BIAS>), grid, block, 0, st, p); break;
+        case EPI_GELU:  hipLaunchKernelGGL((gemm_nt_kernel<NT, MT, EPI_GELU>), grid, block, 0, st, p); break;
+        case EPI_DGELU: hipLaunchKernelGGL((gemm_nt_kernel<NT, MT, EPI_DGELU>), grid, block, 0, st, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t gemm_nt_launch(const GemmNtParams& p, const GemmNtPlan& pl, int epi, hipStream_t st) {
+    if (p.M <= 0) return hipSuccess;
+    if (pl.NT == 4) return launch_nt<4, 4>(p, pl, epi, st);
+    if (pl.NT == 8) return launch_nt<8, 3>(p, pl, epi, st);
+    return launch_nt<13, 2>(p, pl, epi, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemm_tn: every wave owns a (KT*16 i) x (DT*16 j) tile of C[i,j] = sum_r A[r,i] B[r,j] and a row range.
+// slab layout: ws[split][j][ldws] (transposed, float4 along i);  colsum[split][i] = sum_r A[r,i] (tiles j0 == 0).
+template <int KT, int DT>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTnParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int ti = blockIdx.x % p.nti, tj = blockIdx.x / p.nti;
+    const int i0 = ti * (KT * 16), j0 = tj * (DT * 16);
+    const int split = blockIdx.y * 4 + wave;
+    if (split >= p.nsplit) return;
+    const int r_lo = split * p.rps;
+    const int r_hi = min(p.R, r_lo + p.rps);
+    const int nrows = r_hi - r_lo;
+    const int nsteps = nrows > 0 ? (nrows + 3) >> 2 : 0;
+
+    // descriptors start at this wave's first row; rows >= r_hi read 0.  Columns past the matrix edge read
+    // whatever follows in memory (finite) and only feed outputs that are never stored.
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.A) + (size_t)r_lo * p.lda, 0, nrows > 0 ? ((nrows - 1) * p.lda + p.acols) * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.B) + (size_t)r_lo * p.ldb, 0, nrows > 0 ? ((nrows - 1) * p.ldb + p.bcols) * 4 : 0, 0x00020000);
+    const unsigned va = (unsigned)(q * p.lda + i0 + r16) * 4u;
+    const unsigned vb = (unsigned)(q * p.ldb + j0 + r16) * 4u;
+    const int astep = p.lda * 16, bstep = p.ldb * 16;
+
+    f32x4 C[KT][DT];
+#pragma unroll
+    for (int it = 0; it < KT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < DT; ++jt) C[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float cs[KT];
+#pragma unroll
+    for (int it = 0; it < KT; ++it) cs[it] = 0.f;
+
+    float a0[KT], b0[DT], a1[KT], b1[DT];
+    auto load_step = [&](float (&a)[KT], float (&b)[DT], int s) {
+#pragma unroll
+        for (int it = 0; it < KT; ++it) a[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, va + 64 * it, s * astep, 0));
+#pragma unroll
+        for (int jt = 0; jt < DT; ++jt) b[jt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, vb + 64 * jt, s * bstep, 0));
+    };
+    auto mfma_batch = [&](const float (&a)[KT], const float (&b)[DT]) {
+#pragma unroll
+        for (int it = 0; it < KT; ++it) {
+            cs[it] += a[it];
+#pragma unroll
+            for (int jt = 0; jt < DT; ++jt) C[it][jt] = mfma16(a[it], b[jt], C[it][jt]);
+        }
+    };
+    if (nsteps > 0) load_step(a0, b0, 0);
+    for (int s = 0; s < nsteps; s += 2) {
+        if (s + 1 < nsteps) load_step(a1, b1, s + 1);
+        mfma_batch(a0, b0);
+        if (s + 1 < nsteps) {
+            if (s + 2 < nsteps) load_step(a0, b0, s + 2);
+            mfma_batch(a1, b1);
+        }
+    }
+
+    float* wsp = p.ws + (size_t)split * p.ncols_j * p.ldws;
+#pragma unroll
+    for (int jt = 0; jt < DT; ++jt) {
+        const int j = j0 + 16 * jt + r16;
+#pragma unroll
+        for (int it = 0; it < KT; ++it) {
+            const int i = i0 + 16 * it + 4 * q;
+            if (j < p.ncols_j && i < p.ldws) *reinterpret_cast<f32x4*>(wsp + (size_t)j * p.ldws + i) = C[it][jt];
+        }
+    }
+    if (p.colsum && tj == 0) {
+#pragma unroll
+        for (int it = 0; it < KT; ++it) {
+            float v = cs[it];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const int i = i0 + 16 * it + r16;
+            if (q == 0 && i < p.ldws) p.colsum[(size_t)split * p.ldws + i] = v;
+        }
+    }
+#endif
+}
+
+GemmTnPlan gemm_tn_plan(int ncols_i, int ncols_j, int R, int target_waves) {
+    GemmTnPlan pl;
+    const int ni16 = (ncols_i + 15) / 16, nj16 = (ncols_j + 15) / 16;
+    // 5x5 or 4x4 tiles of 16: the shape with fewer padded tiles
+    const long w5 = (long)((ni16 + 4) / 5) * ((nj16 + 4) / 5) * 25, w4 = (long)((ni16 + 3) / 4) * ((nj16 + 3) / 4) * 16;
+    pl.T = w5 <= w4 ? 5 : 4;
+    pl.nti = (ni16 + pl.T - 1) / pl.T;
+    pl.ntj = (nj16 + pl.T - 1) / pl.T;
+    const int tiles = pl.nti * pl.ntj;
+    int ns = target_waves / tiles / 4 * 4;
+    if (ns < 4) ns = 4;
+    const int max_ns = (R + 63) / 64;                 // at least 64 rows per split
+    if (ns > max_ns) ns = max_ns < 1 ? 1 : max_ns;
+    pl.rps = ((R + ns - 1) / ns + 3) / 4 * 4;        // multiple of 4 rows
+    if (pl.rps < 4) pl.rps = 4;
+    pl.nsplit = (R + pl.rps - 1) / pl.rps;
+    if (pl.nsplit < 1) pl.nsplit = 1;
+    return pl;
+}
+
+hipError_t gemm_tn_launch(GemmTnParams p, const GemmTnPlan& pl, hipStream_t st) {
+    p.nti = pl.nti; p.nsplit = pl.nsplit; p.rps = pl.rps;
+    const dim3 grid(pl.nti * pl.ntj, (pl.nsplit + 3) / 4), block(256);
+    if (pl.T == 5) hipLaunchKernelGGL((gemm_tn_kernel<5, 5>), grid, block, 0, st, p);
+    else           hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), grid, block, 0, st, p);
+    return hipGetLastError();
+}
+
+}  // namespace nrm

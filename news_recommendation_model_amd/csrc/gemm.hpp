@@ -1,0 +1,36 @@
+// Parameter blocks of the dense-layer GEMMs (gemm.hip), shared with capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nrm {
+
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_DGELU = 2 };
+
+struct GemmNtParams {
+    const float* x; int ldx, xcols;       // [M, ldx]; xcols = readable floats per row (<= ldx)
+    const float* wp; unsigned wp_bytes;   // packed weight rows (pack_rows_kernel)
+    int rows;                             // padded packed rows = nchunks * NT * 16
+    const float* bias; int N;             // [N] or nullptr
+    float* y; int ldy;                    // [M, ldy]
+    float* z; int ldz;                    // EPI_GELU: pre-activation out, EPI_DGELU: pre-activation in
+    int M, kchunks;
+};
+struct GemmNtPlan { int NT, MT, nchunks, rows; };
+GemmNtPlan gemm_nt_plan(int N);
+hipError_t gemm_nt_launch(const GemmNtParams& p, const GemmNtPlan& pl, int epi, hipStream_t st);
+hipError_t pack_rows_launch(const float* src, long rs, long cs, int nrows, int ncols, int rows, int kchunks,
+                            float* packed, hipStream_t st);
+
+struct GemmTnParams {
+    const float* A; int lda, acols;       // [R, lda]   i-columns
+    const float* B; int ldb, bcols;       // [R, ldb]   j-columns
+    float* ws; int ldws;                  // [nsplit][ncols_j][ldws]   C^T partial slabs
+    float* colsum;                        // [nsplit][ldws] column sums of A, or nullptr
+    int R, ncols_j;
+    int nti, nsplit, rps;                 // filled by gemm_tn_launch from the plan
+};
+struct GemmTnPlan { int T, nti, ntj, nsplit, rps; };
+GemmTnPlan gemm_tn_plan(int ncols_i, int ncols_j, int R, int target_waves);
+hipError_t gemm_tn_launch(GemmTnParams p, const GemmTnPlan& pl, hipStream_t st);
+
+}  // namespace nrm

@@ -1,0 +1,126 @@
+// BatchNorm1d over the [B*T, N] head rows (reference models/user_model.py:18,32: nn.BatchNorm1d, eps 1e-5,
+// biased variance for normalisation) as HBM-bound column kernels.  gfx950 only.
+//   colred_kernel<0>   s0[n] += sum_r x                              (mean)
+//   colred_kernel<1>   s0[n] += sum_r (x - mean)^2                   (two-pass variance: no cancellation)
+//   colred_kernel<2>   s0[n] += sum_r dy ; s1[n] += sum_r dy * (x - mean) * rstd       (d beta, d gamma)
+//   bn_apply_kernel    y = (x - mean) * rstd * gamma + beta
+//   bn_bwd_kernel      dx = gamma * rstd * (dy - s0/R - xhat * s1/R)    (train)   |  gamma * rstd * dy  (eval)
+// Layout: thread = one float4 of columns; blockDim (32, 8); a workgroup sweeps `rpb` rows of a 128-column slab
+// and adds its partial sums with float atomics (R/rpb adds per column).
+#include "common.hpp"
+#include "head.hpp"
+
+namespace nrm {
+
+template <int MODE>
+__global__ __launch_bounds__(256) void colred_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     float* __restrict__ s0, float* __restrict__ s1,
+                                                     int R, int N, int ld, int rpb) {
+    __shared__ f32x4 red[2][8][32];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int col = blockIdx.x * 128 + 4 * tx;
+    const bool cok = col < N;                       // N % 4 == 0
+    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0, mu = a0, rs = a0;
+    if (cok && MODE >= 1) mu = *reinterpret_cast<const f32x4*>(mean + col);
+    if (cok && MODE == 2) rs = *reinterpret_cast<const f32x4*>(rstd + col);
+    const int r_lo = blockIdx.y * rpb, r_hi = min(R, r_lo + rpb);
+    if (cok) {
+        for (int r = r_lo + ty; r < r_hi; r += 8) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)r * ld + col);
+            if (MODE == 0) a0 += xv;
+            else if (MODE == 1) { const f32x4 d = xv - mu; a0 += d * d; }
+            else {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(dy + (size_t)r * ld + col);
+                a0 += g;
+                a1 += g * (xv - mu) * rs;
+            }
+        }
+    }
+    red[0][ty][tx] = a0;
+    if (MODE == 2) red[1][ty][tx] = a1;
+    __syncthreads();
+    if (ty == 0 && cok) {
+        f32x4 t0 = red[0][0][tx], t1 = red[1][0][tx];
+#pragma unroll
+        for (int y = 1; y < 8; ++y) { t0 += red[0][y][tx]; if (MODE == 2) t1 += red[1][y][tx]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(s0 + col + e, t0[e]);
+            if (MODE == 2) atomicAdd(s1 + col + e, t1[e]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ y,
+                                                       long R, int N, int ld) {
+    const int n4 = N >> 2;
+    const long total = R * n4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / n4;
+        const int col = (int)(i - r * n4) * 4;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * ld + col);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + col), rs = *reinterpret_cast<const f32x4*>(rstd + col);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + col), b = *reinterpret_cast<const f32x4*>(beta + col);
+        *reinterpret_cast<f32x4*>(y + r * ld + col) = (xv - mu) * rs * g + b;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ s0,
+                                                     const float* __restrict__ s1, float* __restrict__ dx,
+                                                     long R, int N, int ld, int training) {
+    const int n4 = N >> 2;
+    const long total = R * n4;
+    const float invR = 1.0f / (float)R;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / n4;
+        const int col = (int)(i - r * n4) * 4;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * ld + col);
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + col), ga = *reinterpret_cast<const f32x4*>(gamma + col);
+        f32x4 out;
+        if (training) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * ld + col);
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + col);
+            const f32x4 a = *reinterpret_cast<const f32x4*>(s0 + col), b = *reinterpret_cast<const f32x4*>(s1 + col);
+            const f32x4 xh = (xv - mu) * rs;
+            out = ga * rs * (g - a * invR - xh * b * invR);
+        } else {
+            out = ga * rs * g;
+        }
+        *reinterpret_cast<f32x4*>(dx + r * ld + col) = out;
+    }
+}
+
+hipError_t colred_launch(int mode, const float* x, const float* dy, const float* mean, const float* rstd,
+                         float* s0, float* s1, int R, int N, int ld, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    const int rpb = 256;
+    const dim3 grid((N + 127) / 128, (R + rpb - 1) / rpb), block(32, 8);
+    if (mode == 0) hipLaunchKernelGGL(colred_kernel<0>, grid, block, 0, st, x, dy, mean, rstd, s0, s1, R, N, ld, rpb);
+    else if (mode == 1) hipLaunchKernelGGL(colred_kernel<1>, grid, block, 0, st, x, dy, mean, rstd, s0, s1, R, N, ld, rpb);
+    else if (mode == 2) hipLaunchKernelGGL(colred_kernel<2>, grid, block, 0, st, x, dy, mean, rstd, s0, s1, R, N, ld, rpb);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+static int ew_blocks(long total) { long b = (total + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+
+hipError_t bn_apply_launch(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                           float* y, long R, int N, int ld, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(R * (N >> 2))), dim3(256), 0, st, x, mean, rstd, gamma, beta, y, R, N, ld);
+    return hipGetLastError();
+}
+
+hipError_t bn_bwd_launch(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                         const float* s0, const float* s1, float* dx, long R, int N, int ld, int training, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3(ew_blocks(R * (N >> 2))), dim3(256), 0, st, x, dy, mean, rstd, gamma, s0, s1, dx, R, N, ld, training);
+    return hipGetLastError();
+}
+
+}  // namespace nrm

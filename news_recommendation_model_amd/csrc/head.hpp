@@ -1,0 +1,12 @@
+// Launchers of the BatchNorm column kernels (head.hip), shared with capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nrm {
+hipError_t colred_launch(int mode, const float* x, const float* dy, const float* mean, const float* rstd,
+                         float* s0, float* s1, int R, int N, int ld, hipStream_t st);
+hipError_t bn_apply_launch(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                           float* y, long R, int N, int ld, hipStream_t st);
+hipError_t bn_bwd_launch(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                         const float* s0, const float* s1, float* dx, long R, int N, int ld, int training, hipStream_t st);
+}  // namespace nrm

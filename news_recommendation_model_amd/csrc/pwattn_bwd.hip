@@ -4,7 +4,7 @@
 //                            s[m]   = b2 + sum_k w2[k] gelu(z[m,k]),      m = (b,t,h)
 // Given ds[m] = dL/ds[m] and the saved z:
 //   (1) bwd_dz_kernel      dz[m,k] = ds[m] * w2[k] * gelu'(z[m,k])   (in place over z)
-//                          dw2[k] += sum_m ds[m] * gelu(z[m,k])
+//                          dw2[k] += sum_m ds[m] * gelu(z[m,k]);  du = sum_t dz;  dv = sum_h dz
 //   (2) bwd_e_kernel       for every group g (one (b,t) in pass 1, one (b,h) in pass 2):
 //                              E_g[k,d] = sum_r X_g[r,k] * Y_g[r,d]
 //                          pass 1: X_g = dz[b,t,:,:] (r = h), Y_g = h[b]    -> dt[b,t,d] = sum_k W_p[k,d] E_g[k,d]
@@ -13,68 +13,85 @@
 //      Both passes together are exactly the 2x-forward FLOPs of a GEMM backward; dW_p is accumulated in
 //      registers across the groups a wave walks (one partial slab per split, summed after), and an output
 //      row receives one contiguous float-atomic add per k-range (5 at D=400).
-//   du = sum_t dz, dv = sum_h dz and the side-projection gradients are plain reductions/GEMMs done by the
-//   caller.
+//   The side-projection gradients (from du, dv) are plain GEMMs done by the caller.
 #include "common.hpp"
 #include "pwattn.hpp"
 
 namespace nrm {
 
 // ---------------------------------------------------------------------------------------------
-// (1) elementwise: dz in place + dw2 partial sums.  blockDim = (64, 4): x walks float4 columns, y rows.
-constexpr int DZ_MAXC = 4;      // float4 columns per thread  -> D <= 1024
-
+// (1) one pass over z: dz in place, plus every reduction of dz that does not need a contraction
+//       du[b,h,k] = sum_t dz[b,t,h,k]     dv[b,t,k] = sum_h dz[b,t,h,k]     dw2[k] += sum ds*gelu(z)
+//     workgroup = (one impression b) x (one slab of 128 columns); blockDim = (32 float4 columns, 8 rows).
+//     dv is a register sum over the inner h loop; du lives in LDS [H][128] (every (h, column) cell is
+//     owned by exactly one thread: h % 8 == ty), so z/dz are touched exactly once (HBM-bound kernel).
 __global__ __launch_bounds__(256) void bwd_dz_kernel(float* __restrict__ z, const float* __restrict__ ds,
                                                      const float* __restrict__ w2, float* __restrict__ dw2,
-                                                     long M, int D) {
-    __shared__ f32x4 red[4][64];
+                                                     float* __restrict__ du, float* __restrict__ dv,
+                                                     int T, int H, int D) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // [H][128] du slab | [8][32] float4 scratch
+    f32x4* du_l = reinterpret_cast<f32x4*>(sm);                     // [H][32] float4
+    f32x4* red = du_l + H * 32;                                     // [8][32]
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int C4 = D >> 2;
-    f32x4 w[DZ_MAXC], acc[DZ_MAXC];
-#pragma unroll
-    for (int j = 0; j < DZ_MAXC; ++j) {
-        const int c = tx + 64 * j;
-        w[j] = c < C4 ? *reinterpret_cast<const f32x4*>(w2 + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    for (long row = (long)blockIdx.x * 4 + ty; row < M; row += (long)gridDim.x * 4) {
-        const float g = ds[row];
-        float* zr = z + row * D;
-#pragma unroll
-        for (int j = 0; j < DZ_MAXC; ++j) {
-            const int c = tx + 64 * j;
-            if (c < C4) {
-                const f32x4 zz = *reinterpret_cast<const f32x4*>(zr + 4 * c);
+    const int b = blockIdx.y;
+    const int col = blockIdx.x * 128 + 4 * tx;
+    const bool cok = col < D;                                        // D % 4 == 0
+    const f32x4 w = cok ? *reinterpret_cast<const f32x4*>(w2 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int h = ty; h < H; h += 8) du_l[h * 32 + tx] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 aw = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < T; ++t) {
+        const long row0 = ((long)b * T + t) * H;
+        f32x4 av = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (cok) {
+            for (int h = ty; h < H; h += 8) {
+                const float g = ds[row0 + h];
+                float* zr = z + (row0 + h) * D + col;
+                const f32x4 zz = *reinterpret_cast<const f32x4*>(zr);
                 f32x4 dz;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const GeluParts gp = gelu_parts(zz[e]);
-                    acc[j][e] = fmaf(g * zz[e], gp.cdf, acc[j][e]);                       // ds * gelu(z)
-                    dz[e] = g * w[j][e] * fmaf(zz[e] * 0.39894228040143267794f, gp.e, gp.cdf);
+                    aw[e] = fmaf(g * zz[e], gp.cdf, aw[e]);                          // ds * gelu(z)
+                    dz[e] = g * w[e] * fmaf(zz[e] * 0.39894228040143267794f, gp.e, gp.cdf);
                 }
-                *reinterpret_cast<f32x4*>(zr + 4 * c) = dz;
+                *reinterpret_cast<f32x4*>(zr) = dz;
+                av += dz;
+                du_l[h * 32 + tx] += dz;
             }
         }
-    }
-#pragma unroll
-    for (int j = 0; j < DZ_MAXC; ++j) {
-        const int c = tx + 64 * j;
-        red[ty][tx] = acc[j];
+        red[ty * 32 + tx] = av;
         __syncthreads();
-        if (ty == 0 && c < C4) {
-            const f32x4 sum = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+        if (ty == 0 && cok) {
+            f32x4 sum = red[tx];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(dw2 + 4 * c + e, sum[e]);
+            for (int y = 1; y < 8; ++y) sum += red[y * 32 + tx];
+            *reinterpret_cast<f32x4*>(dv + ((long)b * T + t) * D + col) = sum;
         }
         __syncthreads();
+    }
+    if (cok)
+        for (int h = ty; h < H; h += 8) *reinterpret_cast<f32x4*>(du + ((long)b * H + h) * D + col) = du_l[h * 32 + tx];
+    red[ty * 32 + tx] = aw;
+    __syncthreads();
+    if (ty == 0 && cok) {
+        f32x4 sum = red[tx];
+#pragma unroll
+        for (int y = 1; y < 8; ++y) sum += red[y * 32 + tx];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(dw2 + col + e, sum[e]);
     }
 }
 
-hipError_t bwd_dz_launch(float* z, const float* ds, const float* w2, float* dw2, long M, int D, hipStream_t st) {
-    if (M <= 0) return hipSuccess;
-    long nb = (M + 3) / 4;
-    if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(bwd_dz_kernel, dim3((unsigned)nb), dim3(64, 4), 0, st, z, ds, w2, dw2, M, D);
+hipError_t bwd_dz_launch(float* z, const float* ds, const float* w2, float* dw2, float* du, float* dv,
+                         int B, int T, int H, int D, hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    const size_t shm = ((size_t)H * 32 + 8 * 32) * sizeof(f32x4);
+    if (shm > 160 * 1024) return hipErrorInvalidValue;
+    if (shm > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)bwd_dz_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(bwd_dz_kernel, dim3((D + 127) / 128, B), dim3(32, 8), shm, st, z, ds, w2, dw2, du, dv, T, H, D);
     return hipGetLastError();
 }
 

@@ -42,7 +42,11 @@ class MLP(nn.Module):
 
     def forward(self, x):
         ops._require_gpu(x)
-        return self.fc2(self.activation(self.fc1(x)))
+        if isinstance(self.activation, nn.GELU) and self.activation.approximate == "none":
+            hidden = ops.linear(x, self.fc1.weight, self.fc1.bias, gelu=True)      # fused bias + exact GELU
+        else:
+            hidden = self.activation(ops.linear(x, self.fc1.weight, self.fc1.bias))
+        return ops.linear(hidden, self.fc2.weight, self.fc2.bias)
 
 
 def _scores(mlp: MLP, target, history):
@@ -128,7 +132,7 @@ class UserInvariantInterestModel(nn.Module):
 
         lab_h = torch.cat((self.feature_embedding(cat_h, sub_h, sen_h, typ_h), self.time_embedding(time_h),
                            read_h, scroll_h), dim=2)
-        lab_h = self.w1(lab_h)
+        lab_h = ops.linear(lab_h, self.w1.weight, self.w1.bias)
         lab_t = torch.cat((self.feature_embedding(cat_t, sub_t, sen_t, typ_t), self.time_embedding(time_t)), dim=2)
         ec = torch.cat((lab_t, ti_t), dim=2)
 
@@ -177,7 +181,7 @@ class UserModel(nn.Module):
         e = torch.cat((eu_H, eu_L, ec), dim=2)
         B, T, N = e.shape
         rows = e.reshape(B * T, N)
-        gated = self.gate(self.bn(rows)) * rows            # the gate multiplies the RAW concat
+        gated = self.gate(ops.batch_norm(rows, self.bn)) * rows     # the gate multiplies the RAW concat
         return self.out_mlp(self.mlp(gated)).reshape(B, T)
 
     def loss(self, id, out, label, alpha=0.95):

@@ -40,8 +40,8 @@ class _PointwiseAttentionScores(torch.autograd.Function):
         w_h, w_t, w_d = w1[:, :D], w1[:, D:2 * D], w1[:, 2 * D:3 * D]
         a_h = w_h - w_d
         a_t = w_t + w_d
-        u = torch.addmm(b1, h.reshape(B * H, D), a_h.t())          # [B*H, D]
-        v = t.reshape(B * T, D) @ a_t.t()                            # [B*T, D]
+        u, _ = _gemm_nt(h.reshape(B * H, D), a_h.contiguous(), D, 1, D, D, b1, 0)      # [B*H, D]
+        v, _ = _gemm_nt(t.reshape(B * T, D), a_t.contiguous(), D, 1, D, D, None, 0)    # [B*T, D]
         need_grad = any(ctx.needs_input_grad)
         st = native.stream_ptr()
         packed = torch.empty(native.load().nrm_pwattn_packed_floats(D), dtype=torch.float32, device=t.device)
@@ -64,22 +64,23 @@ class _PointwiseAttentionScores(torch.autograd.Function):
         st = native.stream_ptr()
         ds = _f32c(ds)
         dw2 = torch.zeros(D, dtype=torch.float32, device=t.device)
-        # z -> dz in place (the saved tensor is consumed: a second backward through it is not supported)
+        # one pass over z: z -> dz in place (the saved tensor is consumed: a second backward through it is
+        # not supported), du = sum_t dz, dv = sum_h dz, dw2
+        du = torch.empty(B, H, D, dtype=torch.float32, device=t.device)
+        dv = torch.empty(B, T, D, dtype=torch.float32, device=t.device)
         native.call("nrm_pwattn_bwd_dz", native.ptr(z), native.ptr(ds), native.ptr(w2v), native.ptr(dw2),
-                    B * T * H, D, st)
+                    native.ptr(du), native.ptr(dv), B, T, H, D, st)
         dz = z
         db2 = ds.sum().reshape(1)
-        du = dz.sum(dim=1)                                   # [B,H,D]
-        dv = dz.sum(dim=2)                                   # [B,T,D]
-        db1 = du.sum(dim=(0, 1))
         w_h, w_t, w_d = w1[:, :D], w1[:, D:2 * D], w1[:, 2 * D:3 * D]
         a_h = w_h - w_d
         a_t = w_t + w_d
         du2, dv2 = du.reshape(B * H, D), dv.reshape(B * T, D)
-        da_h = du2.t() @ h.reshape(B * H, D)
-        da_t = dv2.t() @ t.reshape(B * T, D)
-        dh = (du2 @ a_h).reshape(B, H, D)
-        dt = (dv2 @ a_t).reshape(B, T, D)
+        da_h, db1 = _gemm_tn(du2, h.reshape(B * H, D), True)      # du^T h, and db1 = column sums of du
+        da_t, _ = _gemm_tn(dv2, t.reshape(B * T, D), False)
+        a_hc, a_tc = a_h.contiguous(), a_t.contiguous()
+        dh = _gemm_nt(du2, a_hc, 1, D, D, D, None, 0)[0].reshape(B, H, D).contiguous()     # du A_h
+        dt = _gemm_nt(dv2, a_tc, 1, D, D, D, None, 0)[0].reshape(B, T, D).contiguous()     # dv A_t
         nsplit = native.load().nrm_pwattn_bwd_nsplit(B, T, H, D)
         ws = torch.empty(nsplit, D, D, dtype=torch.float32, device=t.device)
         wp = w1[:, 3 * D:]                                   # view, row stride 4D
@@ -97,3 +98,154 @@ class _PointwiseAttentionScores(torch.autograd.Function):
 def pointwise_attention_scores(target, history, fc1_weight, fc1_bias, fc2_weight, fc2_bias):
     """[B,T,D] x [B,H,D] -> [B,T,H] scores (fp32)."""
     return _PointwiseAttentionScores.apply(target, history, fc1_weight, fc1_bias, fc2_weight, fc2_bias)
+
+
+# ------------------------------------------------------------------------------------------------ dense layers
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+def _rows(x):
+    """A 2-D fp32 view the GEMM kernels can stream: unit column stride, row stride a multiple of 4 floats,
+    16-byte aligned rows.  Anything else is copied once into a zero-padded buffer (padding must be finite)."""
+    if (x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0
+            and x.stride(0) >= x.shape[1] and x.data_ptr() % 16 == 0):
+        return x
+    buf = torch.zeros(x.shape[0], _pad4(x.shape[1]), dtype=torch.float32, device=x.device)
+    buf[:, :x.shape[1]] = x
+    return buf[:, :x.shape[1]]
+
+
+def _gemm_nt(x, w_src, row_stride, col_stride, n_out, k_red, bias, epilogue, z=None):
+    """y[M, n_out] = epilogue(x[M, k_red] * Wlogical^T), Wlogical[r, c] = w_src[r*row_stride + c*col_stride]."""
+    lib = native.load()
+    st = native.stream_ptr()
+    M = x.shape[0]
+    packed = torch.empty(lib.nrm_gemm_packed_floats(n_out, k_red), dtype=torch.float32, device=x.device)
+    native.call("nrm_gemm_pack", native.ptr(w_src), row_stride, col_stride, n_out, k_red, native.ptr(packed), st)
+    ldy = _pad4(n_out)
+    y = torch.empty(M, ldy, dtype=torch.float32, device=x.device)
+    if epilogue == 1:
+        z = torch.empty(M, ldy, dtype=torch.float32, device=x.device)
+    native.call("nrm_gemm_nt", native.ptr(x), x.stride(0), M, native.ptr(packed), n_out, k_red,
+                native.ptr(bias) if bias is not None else None, native.ptr(y), ldy,
+                native.ptr(z) if z is not None else None, z.stride(0) if z is not None else 0, epilogue, st)
+    return y[:, :n_out], (z[:, :n_out] if epilogue == 1 else None)
+
+
+def _gemm_tn(a, b, want_colsum):
+    """(sum_r a[r,i] b[r,j]) as [ni, nj], and optionally sum_r a[r,i]."""
+    lib = native.load()
+    st = native.stream_ptr()
+    R, ni = a.shape
+    nj = b.shape[1]
+    nsplit = lib.nrm_gemm_tn_nsplit(ni, nj, R)
+    ldws = _pad4(ni)
+    ws = torch.empty(nsplit, nj, ldws, dtype=torch.float32, device=a.device)
+    cs = torch.empty(nsplit, ldws, dtype=torch.float32, device=a.device) if want_colsum else None
+    native.call("nrm_gemm_tn", native.ptr(a), a.stride(0), ni, native.ptr(b), b.stride(0), nj, R,
+                native.ptr(ws), ldws, native.ptr(cs) if cs is not None else None, st)
+    c = ws.sum(dim=0)[:, :ni].t()
+    return c, (cs.sum(dim=0)[:ni] if want_colsum else None)
+
+
+class _Linear(torch.autograd.Function):
+    """y = act(x W^T + b) for a 2-D x; act in {none, exact GELU}.  Forward and both gradients run on the
+    fp32 MFMA GEMM kernels (csrc/gemm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gelu):
+        _require_gpu(x, weight)
+        x = _rows(x)
+        w = _f32c(weight)
+        N, K = w.shape
+        if x.shape[1] != K:
+            raise RuntimeError(f"linear: input has {x.shape[1]} features, weight expects {K}")
+        b = _f32c(bias) if bias is not None else None
+        y, z = _gemm_nt(x, w, K, 1, N, K, b, 1 if gelu else 0)
+        ctx.save_for_backward(x, w, z)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, z = ctx.saved_tensors
+        N, K = w.shape
+        if z is not None:
+            dy = torch.ops.aten.gelu_backward(dy, z)            # exact-erf GELU' (elementwise)
+        dy = _rows(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = _gemm_tn(dy, x, ctx.has_bias)              # dW[n,k] = sum_m dy[m,n] x[m,k]
+        if ctx.needs_input_grad[0]:
+            dx, _ = _gemm_nt(dy, w, 1, K, K, N, None, 0)        # dX = dY W : rows of the packed operand = k
+        return dx, dw, (db if ctx.has_bias else None), None
+
+
+def linear(x, weight, bias=None, gelu=False):
+    """nn.Linear (optionally followed by exact GELU) on the last dimension of x."""
+    lead = x.shape[:-1]
+    y = _Linear.apply(x.reshape(-1, x.shape[-1]), weight, bias, bool(gelu))
+    return y.reshape(*lead, weight.shape[0])
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm1d
+class _BatchNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps):
+        _require_gpu(x, weight, bias)
+        x = _rows(x)
+        R, N = x.shape
+        ld = x.stride(0)
+        st = native.stream_ptr()
+        w, b = _f32c(weight), _f32c(bias)
+        if training:
+            s = torch.zeros(2, N, dtype=torch.float32, device=x.device)
+            native.call("nrm_colreduce", 0, native.ptr(x), None, None, None, native.ptr(s[0]), None, R, N, ld, st)
+            mean = s[0] / R
+            native.call("nrm_colreduce", 1, native.ptr(x), None, native.ptr(mean), None, native.ptr(s[1]), None, R, N, ld, st)
+            var = s[1] / R
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                running_var.mul_(1 - momentum).add_(var, alpha=momentum * R / max(R - 1, 1))
+        else:
+            mean, var = _f32c(running_mean), _f32c(running_var)
+        rstd = torch.rsqrt(var + eps)
+        y = torch.empty(R, ld, dtype=torch.float32, device=x.device)
+        native.call("nrm_bn_apply", native.ptr(x), native.ptr(mean), native.ptr(rstd), native.ptr(w), native.ptr(b),
+                    native.ptr(y), R, N, ld, st)
+        ctx.save_for_backward(x, mean, rstd, w)
+        ctx.training = training
+        return y[:, :N]
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, w = ctx.saved_tensors
+        R, N = x.shape
+        st = native.stream_ptr()
+        if not (dy.dim() == 2 and dy.stride(1) == 1 and dy.stride(0) == x.stride(0) and dy.dtype == torch.float32
+                and dy.data_ptr() % 16 == 0):
+            buf = torch.zeros(R, x.stride(0), dtype=torch.float32, device=x.device)
+            buf[:, :N] = dy
+            dy = buf[:, :N]
+        ld = x.stride(0)
+        s = torch.zeros(2, N, dtype=torch.float32, device=x.device)
+        native.call("nrm_colreduce", 2, native.ptr(x), native.ptr(dy), native.ptr(mean), native.ptr(rstd),
+                    native.ptr(s[0]), native.ptr(s[1]), R, N, ld, st)
+        dx = torch.empty(R, ld, dtype=torch.float32, device=x.device)
+        native.call("nrm_bn_backward", native.ptr(x), native.ptr(dy), native.ptr(mean), native.ptr(rstd), native.ptr(w),
+                    native.ptr(s[0]), native.ptr(s[1]), native.ptr(dx), R, N, ld, 1 if ctx.training else 0, st)
+        return dx[:, :N], s[1], s[0], None, None, None, None, None
+
+
+def batch_norm(x, bn):
+    """nn.BatchNorm1d(x) for a 2-D x through the HIP column kernels.  Non-default module configurations
+    (no affine / no running stats / cumulative momentum) and widths that are not a multiple of 4 use the
+    module itself."""
+    if (x.dim() != 2 or x.shape[1] % 4 or not bn.affine or not bn.track_running_stats or bn.momentum is None):
+        return bn(x)
+    training = bn.training
+    if training:
+        bn.num_batches_tracked.add_(1)
+    return _BatchNorm.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, float(bn.momentum),
+                            float(bn.eps))
