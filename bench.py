@@ -133,8 +133,8 @@ def main():
     # same weights on every rank (seed 1), a different batch per rank (seed = rank)
     sd = synth.make_state_dict(dims, seed=1, user_num=user_num, perturb=False)
     model = trainer.build_model(dims, user_num, sd, device=dev).train()
-    opt = trainer.make_optimizer(model)
-    reducer = trainer.FlatGradReducer(model.parameters()) if world > 1 else None
+    opt = trainer.FlatAdam(model)              # Adam(lr 1e-3, wd 1e-5) + zero_grad as one launch; flat grad buffer
+    reducer = None                             # the all-reduce runs on opt.flat_grad (no gather copy)
     batch = synth.make_batch(dims, B, H, T, seed=rank, user_num=user_num, dtype=np.float32)
     tb = trainer.batch_to_device(batch, dev)
 
@@ -184,7 +184,7 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                          "flops_per_launch": flops_per_launch, "mean_launch_ms": round(heavy[dom]["mean_ms"], 4)},
             "kernels": {k: {"launches": v["launches"], "mean_ms": round(v["mean_ms"], 4)} for k, v in kern.items()},
-            "grad_allreduce_bytes": reducer.nbytes if reducer else 0,
+            "grad_allreduce_bytes": opt.nbytes if world > 1 else 0,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(dims, wl, args.cpu_seconds, args.cpu_batch)

@@ -93,6 +93,26 @@ int nrm_bn_backward(const float* x, const float* dy, const float* mean, const fl
                     const float* s0, const float* s1, float* dx, int R, int N, int ld, int training,
                     nrm_stream_t stream);
 
+/* ---- weighted pool (reference models/user_invariant_interest_model.py:86-87, no softmax, no mask)
+ * out[b,i,:] (+)= sum_j W[b,i,j] * X[b,j,:]   W element (b,i,j) at W[b*wsb + i*wsi + j*wsj]; X [B,J,D], out [B,I,D]
+ * contiguous.  forward: W = scores [B,T,H], X = history;  d history: W = scores^T (wsi=1, wsj=H), X = d pooled */
+int nrm_pool_bmm(const float* W, long wsb, long wsi, long wsj, const float* X, float* out,
+                 int B, int I, int J, int D, int accumulate, nrm_stream_t stream);
+/* ds[b,t,h] = sum_d g[b,t,d] * h[b,h,d]   (gradient of the pool w.r.t. the scores; wave shuffle reductions) */
+int nrm_pool_rowdot(const float* g, const float* h, float* ds, int B, int T, int H, int D, nrm_stream_t stream);
+
+/* ---- loss (reference models/user_model.py:37-43): (1-alpha)*BCE(softmax_T(out), y) + alpha*BCE(softmax_T(out +
+ * delta[id]), y), mean over B*T, log clamped at -100.  Writes loss_sum[0] += loss, dout [B,T] = dL/dout and
+ * ddelta[id[b]] += dL/ddelta (loss_sum and ddelta must be zero-initialised).  T <= 256. */
+int nrm_loss_fwd_bwd(const float* out, const float* label, const long* user_id, const float* delta, float alpha,
+                     int B, int T, float* loss_sum, float* dout, float* ddelta, nrm_stream_t stream);
+
+/* ---- Adam over one flat fp32 buffer (reference train.py:48,73-75): g += wd*p; m,v update; bias correction for
+ * `step` (1-based); p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps); optionally zeroes g (optimizer.zero_grad()).
+ * n % 4 == 0, 16-byte aligned buffers. */
+int nrm_adam_step(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, int zero_grad, nrm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

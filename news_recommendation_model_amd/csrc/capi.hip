@@ -7,6 +7,7 @@
 #include "pwattn.hpp"
 #include "gemm.hpp"
 #include "head.hpp"
+#include "pool_loss.hpp"
 
 static thread_local char g_err[512] = "";
 
@@ -202,6 +203,37 @@ int nrm_bn_backward(const float* x, const float* dy, const float* mean, const fl
     if (!dy || !rstd || !gamma || !dx || (training && (!x || !mean || !s0 || !s1)))
         return fail(NRM_EINVAL, "nrm_bn_backward: null pointer");
     return check_hip(nrm::bn_bwd_launch(x, dy, mean, rstd, gamma, s0, s1, dx, R, N, ld, training, (hipStream_t)stream), "bn_backward");
+}
+
+
+// ------------------------------------------------------------------------------------------- pool / loss / Adam
+int nrm_pool_bmm(const float* W, long wsb, long wsi, long wsj, const float* X, float* out,
+                 int B, int I, int J, int D, int accumulate, nrm_stream_t stream) {
+    if (!W || !X || !out) return fail(NRM_EINVAL, "nrm_pool_bmm: null pointer");
+    if (B < 0 || I <= 0 || J <= 0 || D <= 0 || D % 4 || B > 65535) return fail(NRM_EINVAL, "nrm_pool_bmm: B=%d I=%d J=%d D=%d", B, I, J, D);
+    return check_hip(nrm::bmm_rows_launch(W, wsb, wsi, wsj, X, (long)J * D, D, out, (long)I * D, D, B, I, J, D, accumulate,
+                                          (hipStream_t)stream), "pool_bmm");
+}
+
+int nrm_pool_rowdot(const float* g, const float* h, float* ds, int B, int T, int H, int D, nrm_stream_t stream) {
+    if (!g || !h || !ds) return fail(NRM_EINVAL, "nrm_pool_rowdot: null pointer");
+    if (B < 0 || T <= 0 || H <= 0 || D <= 0 || D % 4 || D > 1024 || B > 65535) return fail(NRM_EINVAL, "nrm_pool_rowdot: B=%d T=%d H=%d D=%d", B, T, H, D);
+    return check_hip(nrm::rowdot_launch(g, (long)T * D, D, h, (long)H * D, D, ds, B, T, H, D, (hipStream_t)stream), "pool_rowdot");
+}
+
+int nrm_loss_fwd_bwd(const float* out, const float* label, const long* user_id, const float* delta, float alpha,
+                     int B, int T, float* loss_sum, float* dout, float* ddelta, nrm_stream_t stream) {
+    if (!out || !label || !user_id || !delta || !loss_sum || !dout || !ddelta) return fail(NRM_EINVAL, "nrm_loss_fwd_bwd: null pointer");
+    if (B < 0 || T <= 0 || T > 256) return fail(NRM_EINVAL, "nrm_loss_fwd_bwd: B=%d T=%d (T <= 256)", B, T);
+    return check_hip(nrm::loss_launch(out, label, user_id, delta, alpha, B, T, loss_sum, dout, ddelta, (hipStream_t)stream), "loss");
+}
+
+int nrm_adam_step(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, int zero_grad, nrm_stream_t stream) {
+    if (!p || !g || !m || !v) return fail(NRM_EINVAL, "nrm_adam_step: null pointer");
+    if (n < 0 || n % 4 || step < 1 || !al16(p) || !al16(g) || !al16(m) || !al16(v))
+        return fail(NRM_EINVAL, "nrm_adam_step: n=%ld step=%d (n %% 4 == 0, step >= 1, 16-byte aligned buffers)", n, step);
+    return check_hip(nrm::adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, zero_grad, (hipStream_t)stream), "adam");
 }
 
 }  // extern "C"

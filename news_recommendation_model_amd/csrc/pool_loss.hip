@@ -1,0 +1,214 @@
+// Small kernels around the attention: the un-normalised weighted pool and the training loss.  gfx950 only.
+//
+// pool (reference models/user_invariant_interest_model.py:86-87):  pooled[b,t,:] = sum_h s[b,t,h] * h[b,h,:]
+//   bmm_rows_kernel   out[b,i,:] = sum_j W[b,i,j] * X[b,j,:]      (forward: W = s; backward dh: W = s^T, X = g)
+//   rowdot_kernel     ds[b,t,h]  = sum_d g[b,t,d] * h[b,h,d]      (one wave per (t,h) pair, shuffle reduction)
+// loss (reference models/user_model.py:37-43):
+//   L = (1-alpha) * BCEmean(softmax_T(out), y) + alpha * BCEmean(softmax_T(out + delta[id]), y)
+//   loss_kernel: one wave per impression; softmax max/sum and the row reductions are wave shuffles; writes the
+//   loss partial sum and, analytically, dL/dout and dL/ddelta (BCELoss clamps log at -100; its gradient uses
+//   (p - y) / max(p (1 - p), 1e-12) like torch.nn.BCELoss).
+#include "common.hpp"
+#include "pool_loss.hpp"
+
+namespace nrm {
+
+// blockDim = 64: lane owns one float4 of columns; grid = (column slabs of 256, i tiles of 8, B)
+__global__ __launch_bounds__(64) void bmm_rows_kernel(const float* __restrict__ W, long wsb, long wsi, long wsj,
+                                                      const float* __restrict__ X, long xsb, int ldx,
+                                                      float* __restrict__ out, long osb, int ldo,
+                                                      int I, int J, int D, int accumulate) {
+    const int b = blockIdx.z;
+    const int i0 = blockIdx.y * 8;
+    const int col = blockIdx.x * 256 + 4 * threadIdx.x;
+    if (col >= D) return;                            // D % 4 == 0
+    const float* Wb = W + b * wsb;
+    const float* Xb = X + b * xsb + col;
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < J; ++j) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(Xb + (long)j * ldx);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float w = (i0 + i < I) ? Wb[(long)(i0 + i) * wsi + (long)j * wsj] : 0.f;   // wave-uniform (scalar) load
+            acc[i] += xv * w;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i0 + i < I) {
+            float* o = out + b * osb + (long)(i0 + i) * ldo + col;
+            f32x4 v = acc[i];
+            if (accumulate) v += *reinterpret_cast<const f32x4*>(o);
+            *reinterpret_cast<f32x4*>(o) = v;
+        }
+    }
+}
+
+// one wave per (b, t) row of g, looping over h; blockDim = 256 (4 waves)
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ g, long gsb, int ldg,
+                                                     const float* __restrict__ h, long hsb, int ldh,
+                                                     float* __restrict__ ds, int T, int H, int D) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= T) return;
+    const float* gr = g + b * gsb + (long)t * ldg;
+    const float* hb = h + b * hsb;
+    f32x4 gv[4];                                     // up to 1024 columns per lane-strided float4
+    const int nv = (D + 255) / 256;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int c = 256 * v + 4 * lane;
+        gv[v] = (v < nv && c < D) ? *reinterpret_cast<const f32x4*>(gr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int hh = 0; hh < H; ++hh) {
+        const float* hr = hb + (long)hh * ldh;
+        float acc = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int c = 256 * v + 4 * lane;
+            if (v < nv && c < D) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(hr + c);
+                acc += gv[v][0] * x[0] + gv[v][1] * x[1] + gv[v][2] * x[2] + gv[v][3] * x[3];
+            }
+        }
+        acc = wave_sum64(acc);
+        if (lane == 0) ds[((long)b * T + t) * H + hh] = acc;
+    }
+}
+
+hipError_t bmm_rows_launch(const float* W, long wsb, long wsi, long wsj, const float* X, long xsb, int ldx,
+                           float* out, long osb, int ldo, int B, int I, int J, int D, int accumulate, hipStream_t st) {
+    if (B <= 0 || I <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bmm_rows_kernel, dim3((D + 255) / 256, (I + 7) / 8, B), dim3(64), 0, st,
+                       W, wsb, wsi, wsj, X, xsb, ldx, out, osb, ldo, I, J, D, accumulate);
+    return hipGetLastError();
+}
+
+hipError_t rowdot_launch(const float* g, long gsb, int ldg, const float* h, long hsb, int ldh, float* ds,
+                         int B, int T, int H, int D, hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rowdot_kernel, dim3((T + 3) / 4, B), dim3(256), 0, st, g, gsb, ldg, h, hsb, ldh, ds, T, H, D);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// loss: blockDim = 256 (4 waves = 4 impressions); lane l handles candidates l, l+64, ... (T <= 256)
+__device__ __forceinline__ float wave_max64(float v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out, const float* __restrict__ label,
+                                                   const long* __restrict__ uid, const float* __restrict__ delta,
+                                                   float alpha, int B, int T, float* __restrict__ loss_sum,
+                                                   float* __restrict__ dout, float* __restrict__ ddelta) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float dl = delta[uid[b]];
+    const float inv = 1.0f / ((float)B * (float)T);
+    float o[4], y[4];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int t = lane + 64 * v;
+        o[v] = t < T ? out[(long)b * T + t] : -3.0e38f;
+        y[v] = t < T ? label[(long)b * T + t] : 0.f;
+        mx = fmaxf(mx, o[v]);
+    }
+    mx = wave_max64(mx);
+    float total = 0.f, gsum_shift = 0.f;
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    // the two terms differ by the per-row shift only; softmax(out + c) is computed as written (shift inside exp)
+#pragma unroll
+    for (int term = 0; term < 2; ++term) {
+        const float shift = term ? dl : 0.f;
+        const float wt = term ? alpha : 1.0f - alpha;
+        float e[4], se = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { e[v] = (lane + 64 * v < T) ? __expf((o[v] + shift) - (mx + shift)) : 0.f; se += e[v]; }
+        se = wave_sum64(se);
+        const float rse = 1.0f / se;
+        float dp[4], pdp = 0.f, lsum = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const bool ok = lane + 64 * v < T;
+            const float p = e[v] * rse;
+            const float lp = fmaxf(__logf(p), -100.f), l1p = fmaxf(__logf(1.0f - p), -100.f);
+            lsum += ok ? -(y[v] * lp + (1.0f - y[v]) * l1p) : 0.f;
+            dp[v] = ok ? (p - y[v]) / fmaxf(p * (1.0f - p), 1e-12f) : 0.f;          // d BCE / dp  (torch BCELoss backward)
+            pdp += p * dp[v];
+            e[v] = p;
+        }
+        pdp = wave_sum64(pdp);
+        lsum = wave_sum64(lsum);
+        total += wt * lsum;
+        float gs = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float gg = wt * inv * e[v] * (dp[v] - pdp);                       // softmax backward
+            g[v] += gg;
+            gs += gg;
+        }
+        if (term) gsum_shift = wave_sum64(gs);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int t = lane + 64 * v;
+        if (t < T) dout[(long)b * T + t] = g[v];
+    }
+    if (lane == 0) {
+        atomicAdd(loss_sum, total * inv);
+        atomicAdd(ddelta + uid[b], gsum_shift);
+    }
+}
+
+hipError_t loss_launch(const float* out, const float* label, const long* uid, const float* delta, float alpha,
+                       int B, int T, float* loss_sum, float* dout, float* ddelta, hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(loss_kernel, dim3((B + 3) / 4), dim3(256), 0, st, out, label, uid, delta, alpha, B, T, loss_sum, dout, ddelta);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam over one flat fp32 buffer (reference train.py:48: Adam(lr, weight_decay=1e-5), L2 folded into the
+// gradient, bias-corrected, eps added after the sqrt).  Also zeroes the gradient (optimizer.zero_grad()).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float lr, float b1, float b2,
+                                                   float eps, float wd, float bc1, float bc2_sqrt, int zero_grad) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i], gv = reinterpret_cast<f32x4*>(g)[i];
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gg = fmaf(wd, pv[e], gv[e]);
+            mv[e] = fmaf(b1, mv[e], (1.0f - b1) * gg);
+            vv[e] = fmaf(b2, vv[e], (1.0f - b2) * gg * gg);
+            const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+            pv[e] -= (lr / bc1) * (mv[e] / denom);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+        if (zero_grad) reinterpret_cast<f32x4*>(g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+hipError_t adam_launch(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                       float wd, int step, int zero_grad, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const float bc1 = 1.0f - powf(b1, (float)step), bc2s = sqrtf(1.0f - powf(b2, (float)step));
+    long blocks = ((n >> 2) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, zero_grad);
+    return hipGetLastError();
+}
+
+}  // namespace nrm

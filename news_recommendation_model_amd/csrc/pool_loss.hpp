@@ -1,0 +1,14 @@
+// Launchers of pool_loss.hip, shared with capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nrm {
+hipError_t bmm_rows_launch(const float* W, long wsb, long wsi, long wsj, const float* X, long xsb, int ldx,
+                           float* out, long osb, int ldo, int B, int I, int J, int D, int accumulate, hipStream_t st);
+hipError_t rowdot_launch(const float* g, long gsb, int ldg, const float* h, long hsb, int ldh, float* ds,
+                         int B, int T, int H, int D, hipStream_t st);
+hipError_t loss_launch(const float* out, const float* label, const long* uid, const float* delta, float alpha,
+                       int B, int T, float* loss_sum, float* dout, float* ddelta, hipStream_t st);
+hipError_t adam_launch(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                       float wd, int step, int zero_grad, hipStream_t st);
+}  // namespace nrm

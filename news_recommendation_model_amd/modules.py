@@ -140,8 +140,8 @@ class UserInvariantInterestModel(nn.Module):
         s_lab = self.label_attention(lab_t, lab_h)                     # [B,T,H,1]
         s_ti = self.text_img_attention(ti_t, ti_h)
         # un-normalised weighted pool: sum_h score * history  (no softmax, padding not masked)
-        pooled_lab = torch.bmm(s_lab.squeeze(-1), lab_h)
-        pooled_ti = torch.bmm(s_ti.squeeze(-1), ti_h)
+        pooled_lab = ops.weighted_pool(s_lab.squeeze(-1), lab_h)
+        pooled_ti = ops.weighted_pool(s_ti.squeeze(-1), ti_h)
         return torch.cat((pooled_lab, pooled_ti), dim=2), ec
 
 
@@ -185,6 +185,10 @@ class UserModel(nn.Module):
         return self.out_mlp(self.mlp(gated)).reshape(B, T)
 
     def loss(self, id, out, label, alpha=0.95):
+        if out.shape[1] <= 256:
+            return ops.softmax_bce_loss(out, self.delta, label, id, alpha)
+        # more than 256 candidates per impression: the reference formula on device tensors
+        ops._require_gpu(out)
         y = label.to(torch.float32)
         plain = self.bce_loss(self.softmax(out), y)
         shifted = out + self.delta[id].unsqueeze(1)

@@ -249,3 +249,69 @@ def batch_norm(x, bn):
         bn.num_batches_tracked.add_(1)
     return _BatchNorm.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, float(bn.momentum),
                             float(bn.eps))
+
+
+# ------------------------------------------------------------------------------------------------ pool
+class _WeightedPool(torch.autograd.Function):
+    """pooled[b,t,:] = sum_h s[b,t,h] * h[b,h,:]  (un-normalised, unmasked: reference
+    models/user_invariant_interest_model.py:86-87)."""
+
+    @staticmethod
+    def forward(ctx, s, h):
+        _require_gpu(s, h)
+        s, h = _f32c(s), _f32c(h)
+        B, T, H = s.shape
+        D = h.shape[2]
+        out = torch.empty(B, T, D, dtype=torch.float32, device=h.device)
+        native.call("nrm_pool_bmm", native.ptr(s), T * H, H, 1, native.ptr(h), native.ptr(out), B, T, H, D, 0,
+                    native.stream_ptr())
+        ctx.save_for_backward(s, h)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        s, h = ctx.saved_tensors
+        B, T, H = s.shape
+        D = h.shape[2]
+        g = _f32c(g)
+        st = native.stream_ptr()
+        ds = torch.empty(B, T, H, dtype=torch.float32, device=h.device)
+        native.call("nrm_pool_rowdot", native.ptr(g), native.ptr(h), native.ptr(ds), B, T, H, D, st)
+        dh = torch.empty(B, H, D, dtype=torch.float32, device=h.device)
+        native.call("nrm_pool_bmm", native.ptr(s), T * H, 1, H, native.ptr(g), native.ptr(dh), B, H, T, D, 0, st)
+        return ds, dh
+
+
+def weighted_pool(scores, history):
+    return _WeightedPool.apply(scores, history)
+
+
+# ------------------------------------------------------------------------------------------------ loss
+class _SoftmaxBceLoss(torch.autograd.Function):
+    """The two-term BCE-on-softmax loss of reference models/user_model.py:37-43, value and gradients in one
+    kernel (one wave per impression)."""
+
+    @staticmethod
+    def forward(ctx, out, delta, label, user_id, alpha):
+        _require_gpu(out, delta, label, user_id)
+        B, T = out.shape
+        o = _f32c(out)
+        y = _f32c(label)
+        uid = user_id.to(torch.int64).contiguous()
+        d = _f32c(delta)
+        loss = torch.zeros(1, dtype=torch.float32, device=out.device)
+        dout = torch.empty(B, T, dtype=torch.float32, device=out.device)
+        ddelta = torch.zeros_like(d)
+        native.call("nrm_loss_fwd_bwd", native.ptr(o), native.ptr(y), native.ptr(uid), native.ptr(d), float(alpha),
+                    B, T, native.ptr(loss), native.ptr(dout), native.ptr(ddelta), native.stream_ptr())
+        ctx.save_for_backward(dout, ddelta)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        dout, ddelta = ctx.saved_tensors
+        return dout * gl, ddelta * gl, None, None, None
+
+
+def softmax_bce_loss(out, delta, label, user_id, alpha):
+    return _SoftmaxBceLoss.apply(out, delta, label, user_id, alpha)

@@ -40,6 +40,61 @@ def make_optimizer(model, lr=1e-3):
     return torch.optim.Adam(model.parameters(), lr=lr, weight_decay=1e-5)
 
 
+class FlatAdam:
+    """train.py:48's Adam(lr, weight_decay=1e-5) over ONE flat fp32 buffer.
+
+    Parameters and their ``.grad`` are re-seated as views into two flat buffers (values are preserved, the
+    Module's ``state_dict`` keeps working), so ``step()`` + ``zero_grad()`` is a single HIP kernel launch over
+    all weights and the data-parallel gradient all-reduce runs on ``flat_grad`` without a gather copy."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5):
+        from . import native
+        native.load()
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        if not self.params or not self.params[0].is_cuda:
+            raise RuntimeError("FlatAdam needs the model on an MI355X device (no CPU path)")
+        dev = self.params[0].device
+        offs, n = [], 0
+        for p in self.params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4                      # every parameter starts 16-byte aligned
+        self.n = n
+        self.flat_param = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, offs):
+            view = self.flat_param[o:o + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.steps = 0
+        self.param_groups = [{"lr": lr}]                       # what train.py:57 reads
+
+    @property
+    def nbytes(self):
+        return self.n * 4
+
+    def step(self, zero_grad=True):
+        from . import native
+        self.steps += 1
+        native.call("nrm_adam_step", native.ptr(self.flat_param), native.ptr(self.flat_grad),
+                    native.ptr(self.exp_avg), native.ptr(self.exp_avg_sq), self.n, float(self.param_groups[0]["lr"]),
+                    float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
+                    self.steps, 1 if zero_grad else 0, native.stream_ptr())
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_grad.zero_()
+
+    def all_reduce_grads(self, group=None):
+        """The ONE collective of a data-parallel step: sum the flat gradient over ranks, then average."""
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if world > 1:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)
+            self.flat_grad.mul_(1.0 / world)
+
+
 class FlatGradReducer:
     """Averages the gradients of ``params`` across ranks with ONE all-reduce of a flat fp32 buffer."""
 
@@ -81,10 +136,14 @@ def train_step(model, optimizer, batch, reducer: FlatGradReducer | None = None, 
     out = model(batch["x_history"], batch["x_target"], batch["x_global"])
     loss = model.loss(batch["user_id"], out, batch["label"], alpha)
     loss.backward()
-    if reducer is not None:
-        reducer.reduce()
-    optimizer.step()
-    optimizer.zero_grad(set_to_none=False)
+    if isinstance(optimizer, FlatAdam):
+        optimizer.all_reduce_grads()
+        optimizer.step(zero_grad=True)                # Adam + zero_grad fused in one launch
+    else:
+        if reducer is not None:
+            reducer.reduce()
+        optimizer.step()
+        optimizer.zero_grad(set_to_none=False)
     return loss.detach(), out.detach()
 
 

@@ -134,10 +134,10 @@ def user_model_forward(p, x_history, x_target, x_global, training=True, bn_state
 
 
 def bce_mean(prob, y):
-    """nn.BCELoss(): mean of -(y log p + (1-y) log(1-p)) with both logs clamped at -100."""
-    lp = torch.clamp(torch.log(prob), min=-100.0)
-    l1p = torch.clamp(torch.log(1.0 - prob), min=-100.0)
-    return -(y * lp + (1.0 - y) * l1p).mean()
+    """nn.BCELoss() (models/user_model.py:24): mean of -(y log p + (1-y) log(1-p)) with both logs clamped at
+    -100, and PyTorch's guarded backward (p - y) / max(p (1 - p), 1e-12) -- a hand-written clamp(log p) has a
+    0 * inf = NaN gradient where p underflows, the reference's loss does not."""
+    return F.binary_cross_entropy(prob, y, reduction="mean")
 
 
 def user_model_loss(p, user_id, out, label, alpha=0.95):
