@@ -113,6 +113,26 @@ int nrm_loss_fwd_bwd(const float* out, const float* label, const long* user_id, 
 int nrm_adam_step(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, int zero_grad, nrm_stream_t stream);
 
+/* ---- embedding front end: reference models/user_invariant_interest_model.py:50-71,74-79 (slice_x,
+ * feature_embedding, time_embedding).  x: [nrows, xcols] packed rows (tool/process_data.py:198-240), fp64
+ * (x_is_f64 != 0) or fp32: [year,month,day,hour | text_img P | category | sub-category x n_sub | sentiment x3 |
+ * type | (behaviour != 0: read_time, scroll)].  Writes the label rows lab[nrows, ldlab] = [Emb_cat(cat)+mean
+ * Emb_cat(sub) e0 | ReLU(W_s s + b_s) e1 | Emb_type e2 | sum of 4 time embeddings e3 | (read_time, scroll)] zero
+ * padded to ldlab, and the text/image block ti[nrows, ldti] as fp32.  err[0] is set to 1 on an out-of-range index
+ * (the index is clamped; the reference raises IndexError). */
+int nrm_frontend_fwd(const void* x, int x_is_f64, int nrows, int xcols, int P, int n_sub, int behaviour,
+                     const float* cat_tab, int n_cat, int e0, const float* sen_w, const float* sen_b, int e1,
+                     const float* type_tab, int n_type, int e2,
+                     const float* year_tab, const float* month_tab, const float* day_tab, const float* hour_tab,
+                     int n_year, int n_month, int n_day, int n_hour, int e3,
+                     float* lab, int ldlab, float* ti, int ldti, int* err, nrm_stream_t stream);
+/* backward of the label rows: accumulates (+=, float atomics) the table / sentiment-layer gradients */
+int nrm_frontend_bwd(const void* x, int x_is_f64, int nrows, int xcols, int P, int n_sub, int behaviour,
+                     const float* dlab, int lddl, const float* sen_w, const float* sen_b,
+                     int n_cat, int e0, int e1, int n_type, int e2, int n_year, int n_month, int n_day, int n_hour, int e3,
+                     float* d_cat_tab, float* d_sen_w, float* d_sen_b, float* d_type_tab,
+                     float* d_year_tab, float* d_month_tab, float* d_day_tab, float* d_hour_tab, nrm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

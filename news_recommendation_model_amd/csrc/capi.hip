@@ -8,6 +8,7 @@
 #include "gemm.hpp"
 #include "head.hpp"
 #include "pool_loss.hpp"
+#include "frontend.hpp"
 
 static thread_local char g_err[512] = "";
 
@@ -234,6 +235,53 @@ int nrm_adam_step(float* p, float* g, float* m, float* v, long n, float lr, floa
     if (n < 0 || n % 4 || step < 1 || !al16(p) || !al16(g) || !al16(m) || !al16(v))
         return fail(NRM_EINVAL, "nrm_adam_step: n=%ld step=%d (n %% 4 == 0, step >= 1, 16-byte aligned buffers)", n, step);
     return check_hip(nrm::adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, zero_grad, (hipStream_t)stream), "adam");
+}
+
+
+// ------------------------------------------------------------------------------------------- embedding front end
+static int check_fe(const char* fn, int nrows, int xcols, int P, int n_sub, int behaviour, int e0, int e1, int e2, int e3) {
+    if (nrows < 0 || P <= 0 || n_sub < 0 || e0 <= 0 || e1 <= 0 || e2 <= 0 || e3 <= 0)
+        return fail(NRM_EINVAL, "%s: bad dimension", fn);
+    const int need = 4 + P + 1 + n_sub + 3 + 1 + (behaviour ? 2 : 0);
+    if (xcols < need) return fail(NRM_EINVAL, "%s: packed rows have %d columns, layout needs %d", fn, xcols, need);
+    return NRM_OK;
+}
+
+int nrm_frontend_fwd(const void* x, int x_is_f64, int nrows, int xcols, int P, int n_sub, int behaviour,
+                     const float* cat_tab, int n_cat, int e0, const float* sen_w, const float* sen_b, int e1,
+                     const float* type_tab, int n_type, int e2,
+                     const float* year_tab, const float* month_tab, const float* day_tab, const float* hour_tab,
+                     int n_year, int n_month, int n_day, int n_hour, int e3,
+                     float* lab, int ldlab, float* ti, int ldti, int* err, nrm_stream_t stream) {
+    if (int rc = check_fe("nrm_frontend_fwd", nrows, xcols, P, n_sub, behaviour, e0, e1, e2, e3)) return rc;
+    if (!x || !cat_tab || !sen_w || !sen_b || !type_tab || !year_tab || !month_tab || !day_tab || !hour_tab || !lab || !ti || !err)
+        return fail(NRM_EINVAL, "nrm_frontend_fwd: null pointer");
+    if (ldlab < e0 + e1 + e2 + e3 + (behaviour ? 2 : 0) || ldti < P) return fail(NRM_EINVAL, "nrm_frontend_fwd: ldlab=%d ldti=%d too small", ldlab, ldti);
+    nrm::FrontendParams p = {};
+    p.cat_tab = cat_tab; p.sen_w = sen_w; p.sen_b = sen_b; p.type_tab = type_tab;
+    p.year_tab = year_tab; p.month_tab = month_tab; p.day_tab = day_tab; p.hour_tab = hour_tab;
+    p.n_cat = n_cat; p.n_type = n_type; p.n_year = n_year; p.n_month = n_month; p.n_day = n_day; p.n_hour = n_hour;
+    p.e0 = e0; p.e1 = e1; p.e2 = e2; p.e3 = e3; p.P = P; p.n_sub = n_sub; p.xcols = xcols; p.behaviour = behaviour;
+    p.lab = lab; p.ldlab = ldlab; p.ti = ti; p.ldti = ldti; p.err = err;
+    return check_hip(nrm::frontend_fwd_launch(p, x, x_is_f64, nrows, (hipStream_t)stream), "frontend_fwd");
+}
+
+int nrm_frontend_bwd(const void* x, int x_is_f64, int nrows, int xcols, int P, int n_sub, int behaviour,
+                     const float* dlab, int lddl, const float* sen_w, const float* sen_b,
+                     int n_cat, int e0, int e1, int n_type, int e2, int n_year, int n_month, int n_day, int n_hour, int e3,
+                     float* d_cat_tab, float* d_sen_w, float* d_sen_b, float* d_type_tab,
+                     float* d_year_tab, float* d_month_tab, float* d_day_tab, float* d_hour_tab, nrm_stream_t stream) {
+    if (int rc = check_fe("nrm_frontend_bwd", nrows, xcols, P, n_sub, behaviour, e0, e1, e2, e3)) return rc;
+    if (!x || !dlab || !sen_w || !sen_b || !d_cat_tab || !d_sen_w || !d_sen_b || !d_type_tab || !d_year_tab || !d_month_tab || !d_day_tab || !d_hour_tab)
+        return fail(NRM_EINVAL, "nrm_frontend_bwd: null pointer");
+    if (lddl < e0 + e1 + e2 + e3) return fail(NRM_EINVAL, "nrm_frontend_bwd: lddl=%d too small", lddl);
+    nrm::FrontendParams p = {};
+    p.sen_w = sen_w; p.sen_b = sen_b;
+    p.d_cat_tab = d_cat_tab; p.d_sen_w = d_sen_w; p.d_sen_b = d_sen_b; p.d_type_tab = d_type_tab;
+    p.d_year_tab = d_year_tab; p.d_month_tab = d_month_tab; p.d_day_tab = d_day_tab; p.d_hour_tab = d_hour_tab;
+    p.n_cat = n_cat; p.n_type = n_type; p.n_year = n_year; p.n_month = n_month; p.n_day = n_day; p.n_hour = n_hour;
+    p.e0 = e0; p.e1 = e1; p.e2 = e2; p.e3 = e3; p.P = P; p.n_sub = n_sub; p.xcols = xcols; p.behaviour = behaviour;
+    return check_hip(nrm::frontend_bwd_launch(p, x, x_is_f64, dlab, lddl, nrows, (hipStream_t)stream), "frontend_bwd");
 }
 
 }  // extern "C"

@@ -125,18 +125,21 @@ class UserInvariantInterestModel(nn.Module):
         return (self.year_embedding[0](idx[..., 0]) + self.month_embedding[0](idx[..., 1])
                 + self.day_embedding[0](idx[..., 2]) + self.hour_embedding[0](idx[..., 3]))
 
+    def _embed(self, x, behaviour):
+        """Fused front end (slice_x + feature_embedding + time_embedding [+ read_time, scroll]) on packed rows."""
+        sen = self.sentiment_embedding[0]
+        return ops.frontend(x, behaviour, self._dims.n_subcat, self._dims.pca_vector,
+                            self.category_embedding[0].weight, sen.weight, sen.bias, self.type_embedding[0].weight,
+                            self.year_embedding[0].weight, self.month_embedding[0].weight,
+                            self.day_embedding[0].weight, self.hour_embedding[0].weight)
+
     def forward(self, x_history, x_target):
         ops._require_gpu(x_history, x_target)
-        time_h, ti_h, cat_h, sub_h, sen_h, typ_h, read_h, scroll_h = self.slice_x(x_history.to(torch.float32), 8)
-        time_t, ti_t, cat_t, sub_t, sen_t, typ_t = self.slice_x(x_target.to(torch.float32), 6)
-
-        lab_h = torch.cat((self.feature_embedding(cat_h, sub_h, sen_h, typ_h), self.time_embedding(time_h),
-                           read_h, scroll_h), dim=2)
+        lab_h, ti_h = self._embed(x_history, True)         # [B,H,D_l+2], [B,H,P]
+        lab_t, ti_t = self._embed(x_target, False)         # [B,T,D_l],   [B,T,P]
         lab_h = ops.linear(lab_h, self.w1.weight, self.w1.bias)
-        lab_t = torch.cat((self.feature_embedding(cat_t, sub_t, sen_t, typ_t), self.time_embedding(time_t)), dim=2)
         ec = torch.cat((lab_t, ti_t), dim=2)
 
-        ti_h = ti_h.contiguous()
         s_lab = self.label_attention(lab_t, lab_h)                     # [B,T,H,1]
         s_ti = self.text_img_attention(ti_t, ti_h)
         # un-normalised weighted pool: sum_h score * history  (no softmax, padding not masked)

@@ -315,3 +315,83 @@ class _SoftmaxBceLoss(torch.autograd.Function):
 
 def softmax_bce_loss(out, delta, label, user_id, alpha):
     return _SoftmaxBceLoss.apply(out, delta, label, user_id, alpha)
+
+
+# ------------------------------------------------------------------------------------------------ embedding front end
+_index_error_flag = {}
+
+
+def index_error_flag(device):
+    """Device int32 set to 1 by the front-end kernel when a packed row holds an out-of-range table index (the
+    reference raises IndexError there; the kernel clamps, flags and goes on).  Reading it synchronises, so it is
+    checked by ``check_index_errors`` on request, not on every step."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device(device.type, torch.cuda.current_device())
+    key = str(device)
+    if key not in _index_error_flag:
+        _index_error_flag[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _index_error_flag[key]
+
+
+def check_index_errors(device="cuda"):
+    flag = index_error_flag(device)
+    if int(flag.item()):
+        flag.zero_()
+        raise IndexError("index out of range in a packed feature row (category / type / time table)")
+
+
+class _Frontend(torch.autograd.Function):
+    """Packed rows [R, cols] (fp32 or fp64) -> (label rows [R, e0+e1+e2+e3(+2)], text/image rows [R, P] fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, behaviour, n_sub, P, cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab):
+        _require_gpu(x, cat_tab)
+        if x.dtype not in (torch.float32, torch.float64):
+            x = x.to(torch.float32)
+        x = x.contiguous()
+        R, xcols = x.shape
+        tabs = [_f32c(t) for t in (cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab)]
+        cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab = tabs
+        e0, e1, e2, e3 = cat_tab.shape[1], sen_w.shape[0], type_tab.shape[1], year_tab.shape[1]
+        width = e0 + e1 + e2 + e3 + (2 if behaviour else 0)
+        ldlab, ldti = _pad4(width), _pad4(P)
+        lab = torch.empty(R, ldlab, dtype=torch.float32, device=x.device)
+        ti = torch.empty(R, ldti, dtype=torch.float32, device=x.device)
+        dims = (cat_tab.shape[0], e0, e1, type_tab.shape[0], e2, year_tab.shape[0], month_tab.shape[0],
+                day_tab.shape[0], hour_tab.shape[0], e3)
+        native.call("nrm_frontend_fwd", native.ptr(x), 1 if x.dtype == torch.float64 else 0, R, xcols, P, n_sub,
+                    1 if behaviour else 0, native.ptr(cat_tab), dims[0], e0, native.ptr(sen_w), native.ptr(sen_b), e1,
+                    native.ptr(type_tab), dims[3], e2, native.ptr(year_tab), native.ptr(month_tab), native.ptr(day_tab),
+                    native.ptr(hour_tab), dims[5], dims[6], dims[7], dims[8], e3,
+                    native.ptr(lab), ldlab, native.ptr(ti), ldti, native.ptr(index_error_flag(x.device)),
+                    native.stream_ptr())
+        ctx.save_for_backward(x, sen_w, sen_b)
+        ctx.geom = (behaviour, n_sub, P, dims)
+        ctx.mark_non_differentiable(ti)
+        return lab[:, :width], ti[:, :P]
+
+    @staticmethod
+    def backward(ctx, dlab, _dti):
+        x, sen_w, sen_b = ctx.saved_tensors
+        behaviour, n_sub, P, dims = ctx.geom
+        n_cat, e0, e1, n_type, e2, n_year, n_month, n_day, n_hour, e3 = dims
+        dlab = _rows(dlab)
+        dev = x.device
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+        d_cat, d_sw, d_sb, d_type = z(n_cat, e0), z(e1, 3), z(e1), z(n_type, e2)
+        d_year, d_month, d_day, d_hour = z(n_year, e3), z(n_month, e3), z(n_day, e3), z(n_hour, e3)
+        native.call("nrm_frontend_bwd", native.ptr(x), 1 if x.dtype == torch.float64 else 0, x.shape[0], x.shape[1], P,
+                    n_sub, 1 if behaviour else 0, native.ptr(dlab), dlab.stride(0), native.ptr(sen_w), native.ptr(sen_b),
+                    n_cat, e0, e1, n_type, e2, n_year, n_month, n_day, n_hour, e3,
+                    native.ptr(d_cat), native.ptr(d_sw), native.ptr(d_sb), native.ptr(d_type),
+                    native.ptr(d_year), native.ptr(d_month), native.ptr(d_day), native.ptr(d_hour), native.stream_ptr())
+        return None, None, None, None, d_cat, d_sw, d_sb, d_type, d_year, d_month, d_day, d_hour
+
+
+def frontend(x, behaviour, n_sub, P, cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab):
+    """x [B, N, cols] -> (label rows [B, N, width], text/image rows [B, N, P])."""
+    B, N = x.shape[0], x.shape[1]
+    lab, ti = _Frontend.apply(x.reshape(B * N, x.shape[2]), bool(behaviour), int(n_sub), int(P), cat_tab, sen_w, sen_b,
+                              type_tab, year_tab, month_tab, day_tab, hour_tab)
+    return lab.reshape(B, N, -1) if lab.is_contiguous() else lab.unflatten(0, (B, N)), ti.unflatten(0, (B, N))

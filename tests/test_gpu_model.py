@@ -160,3 +160,19 @@ def test_flat_adam_matches_torch_adam_and_fixture(lib):
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     model.load_state_dict(sd)
     assert model.gate.fc1.weight.data_ptr() >= fopt.flat_param.data_ptr()
+
+
+def test_frontend_flags_out_of_range_index_like_indexerror(lib):
+    """The reference raises IndexError for a category id >= category_label_num (nn.Embedding on CPU); the HIP
+    front end clamps and raises the flag that ops.check_index_errors() turns into IndexError."""
+    from news_recommendation_model_amd import ops
+    case, model, tb, batch, fx = _model_and_batch("tiny_train")
+    model.eval()
+    ops.check_index_errors("cuda")                          # clean
+    bad = tb["x_history"].clone()
+    bad[0, 0, 4 + 64] = 10_000                              # category column of the first history row
+    with torch.no_grad():
+        model(bad, tb["x_target"], tb["x_global"])
+    with pytest.raises(IndexError):
+        ops.check_index_errors("cuda")
+    ops.check_index_errors("cuda")                          # flag is cleared after raising
