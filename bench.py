@@ -116,10 +116,18 @@ def main():
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    # rehearsal on a one-GPU box: NRM_SINGLE_DEVICE=1 puts every rank on cuda:0 and NRM_DIST_BACKEND=gloo replaces
+    # RCCL (which needs one device per rank); the real multi-GPU run uses neither.
+    if os.environ.get("NRM_SINGLE_DEVICE") == "1":
+        local = 0
+    backend = os.environ.get("NRM_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from news_recommendation_model_amd import native, synth, trainer
     from news_recommendation_model_amd.config import Dims, WORKLOADS
@@ -139,6 +147,7 @@ def main():
     tb = trainer.batch_to_device(batch, dev)
 
     def sync():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -157,6 +166,14 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # replicas must still hold identical weights after the timed steps (same init, averaged gradients)
+        chk = torch.stack([opt.flat_param.double().sum(), opt.flat_param.double().abs().sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_in_sync = bool(torch.equal(lo, hi))
+    else:
+        replicas_in_sync = True
 
     # per-kernel launch durations from the event pairs recorded on the launch stream
     per = {}
@@ -184,7 +201,7 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                          "flops_per_launch": flops_per_launch, "mean_launch_ms": round(heavy[dom]["mean_ms"], 4)},
             "kernels": {k: {"launches": v["launches"], "mean_ms": round(v["mean_ms"], 4)} for k, v in kern.items()},
-            "grad_allreduce_bytes": opt.nbytes if world > 1 else 0,
+            "grad_allreduce_bytes": opt.nbytes if world > 1 else 0, "replicas_in_sync": replicas_in_sync,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(dims, wl, args.cpu_seconds, args.cpu_batch)
