@@ -185,6 +185,16 @@ def main():
     flops_per_launch = 2.0 * B * T * H * D * D            # both attentions have width D in BASELINE shapes
     achieved = flops_per_launch / (heavy[dom]["mean_ms"] * 1e-3) / 1e12
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure comes
+    # from the committed rocprofv3 --pmc passes of this same command (profiles/r1_c3_pmc_traffic.json, C3 only)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r1_c3_pmc_traffic.json")
+    if args.workload == "C3-large" and not args.batch and os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom, {}).get("corrected_bytes")
+        except Exception:
+            traffic = None
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         line = {
@@ -198,7 +208,7 @@ def main():
                        "step": "fwd+loss+bwd+allreduce+Adam(wd=1e-5)" if world > 1 else "fwd+loss+bwd+Adam(wd=1e-5)"},
             "loss": round(float(loss), 6),
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "flops_per_launch": flops_per_launch, "mean_launch_ms": round(heavy[dom]["mean_ms"], 4)},
             "kernels": {k: {"launches": v["launches"], "mean_ms": round(v["mean_ms"], 4)} for k, v in kern.items()},
             "grad_allreduce_bytes": opt.nbytes if world > 1 else 0, "replicas_in_sync": replicas_in_sync,

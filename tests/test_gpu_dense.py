@@ -1,0 +1,73 @@
+"""GPU: the dense-layer kernels through the C ABI (nrm_gemm_pack / nrm_gemm_nt / nrm_gemm_tn) and the BatchNorm
+column kernels, against float64 PyTorch on the same inputs.  Shapes cover the head of the model (K or N = 402,
+not a multiple of 4 -> padded leading dimensions), tiny layers (3 -> 8), and ragged row counts."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 402, 1608), (257, 1608, 402), (64, 3, 8), (1000, 402, 1), (33, 66, 64),
+                                   (5, 272, 68), (192, 400, 400)])
+@pytest.mark.parametrize("gelu", [False, True])
+def test_linear_forward_backward(lib, M, K, N, gelu):
+    from news_recommendation_model_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + K + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / np.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.1
+    gy = torch.randn(M, N, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    y_ref = torch.nn.functional.linear(xr, wr, br)
+    if gelu:
+        y_ref = torch.nn.functional.gelu(y_ref)
+    y_ref.backward(gy.double())
+    xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    y = ops.linear(xg, wg, bg, gelu=gelu)
+    y.backward(gy.cuda())
+    assert tuple(y.shape) == (M, N)
+    assert rel_err(y.detach().cpu().numpy(), y_ref.detach().numpy()) < 1e-5
+    assert rel_err(xg.grad.cpu().numpy(), xr.grad.numpy()) < 1e-5
+    assert rel_err(wg.grad.cpu().numpy(), wr.grad.numpy()) < 1e-5
+    assert rel_err(bg.grad.cpu().numpy(), br.grad.numpy()) < 1e-5
+
+
+def test_linear_accepts_strided_and_3d_inputs(lib):
+    from news_recommendation_model_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(4, 9, 70, device="cuda")[:, :, 3:69]            # non-contiguous, 66 features, offset start
+    w = torch.randn(64, 66, device="cuda") * 0.1
+    y = ops.linear(x, w, None)
+    ref = torch.nn.functional.linear(x.double(), w.double())
+    assert tuple(y.shape) == (4, 9, 64)
+    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("R,N", [(1000, 264), (30720, 1608), (7, 8)])
+@pytest.mark.parametrize("training", [True, False])
+def test_batch_norm_matches_torch(lib, R, N, training):
+    from news_recommendation_model_amd import ops
+    torch.manual_seed(R + N)
+    x = (torch.randn(R, N) * 3 + 5).cuda()                          # large mean: two-pass variance must hold up
+    gy = torch.randn(R, N).cuda()
+    ref = torch.nn.BatchNorm1d(N).cuda().double()
+    mine = torch.nn.BatchNorm1d(N).cuda()
+    with torch.no_grad():
+        for m in (ref, mine):
+            m.weight.copy_(torch.linspace(0.5, 1.5, N)); m.bias.copy_(torch.linspace(-1, 1, N))
+            m.running_mean.copy_(torch.linspace(4, 6, N)); m.running_var.copy_(torch.linspace(8, 10, N))
+    ref.train(training); mine.train(training)
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr); yr.backward(gy.double())
+    xm = x.clone().requires_grad_(True)
+    ym = ops.batch_norm(xm, mine); ym.backward(gy)
+    assert rel_err(ym.detach().cpu().numpy(), yr.detach().cpu().numpy()) < 1e-5
+    assert rel_err(xm.grad.cpu().numpy(), xr.grad.cpu().numpy()) < 1e-4
+    assert rel_err(mine.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy()) < 1e-4
+    assert rel_err(mine.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy()) < 1e-4
+    assert rel_err(mine.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy()) < 1e-5
+    assert rel_err(mine.running_var.cpu().numpy(), ref.running_var.cpu().numpy()) < 1e-5
+    assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked)
