@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C3-large")
     ap.add_argument("--batch", type=int, default=None, help="override per-GPU batch")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the step in a HIP graph and time graph replays (per-kernel event timing then "
+                         "comes from 3 extra eager steps outside the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=None)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -152,16 +155,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        trainer.train_step(model, opt, tb, reducer)
-    sync()
-    native.kernel_events = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = trainer.train_step(model, opt, tb, reducer)
-    sync()
+    if args.graph:
+        # per-kernel durations cannot be event-timed inside a graph: take them from 3 eager steps first
+        for _ in range(2):
+            trainer.train_step(model, opt, tb, reducer)
+        sync()
+        native.kernel_events = []
+        for _ in range(3):
+            loss, _ = trainer.train_step(model, opt, tb, reducer)
+        sync()
+        events, native.kernel_events = native.kernel_events, None
+        step = trainer.GraphedTrainStep(model, opt, tb)
+        for _ in range(args.warmup):
+            step.replay()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss, _ = step.replay()
+        sync()
+    else:
+        for _ in range(args.warmup):
+            trainer.train_step(model, opt, tb, reducer)
+        sync()
+        native.kernel_events = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss, _ = trainer.train_step(model, opt, tb, reducer)
+        sync()
     elapsed = time.perf_counter() - t0
-    events, native.kernel_events = native.kernel_events, None
+    if not args.graph:
+        events, native.kernel_events = native.kernel_events, None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -204,7 +227,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: EBNeRD-large-shape synthetic" if args.workload == "C3-large" else args.workload,
                        "per_gpu_batch": B, "global_batch": world * B, "hist": H, "candidates": T, "emb": D,
-                       "user_num": user_num, "parallelism": f"dp{world}",
+                       "user_num": user_num, "parallelism": f"dp{world}", "launch": "hipGraph replay" if args.graph else "eager",
                        "step": "fwd+loss+bwd+allreduce+Adam(wd=1e-5)" if world > 1 else "fwd+loss+bwd+Adam(wd=1e-5)"},
             "loss": round(float(loss), 6),
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,

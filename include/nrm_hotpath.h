@@ -112,6 +112,10 @@ int nrm_loss_fwd_bwd(const float* out, const float* label, const long* user_id, 
  * n % 4 == 0, 16-byte aligned buffers. */
 int nrm_adam_step(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, int zero_grad, nrm_stream_t stream);
+/* the same with the step counter on the device (state = float[4]: {step, 1-beta1^step, sqrt(1-beta2^step), -},
+ * zero-initialised by the caller, advanced by the call): safe to capture in a hipGraph and replay */
+int nrm_adam_step_dev(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, float* state, int zero_grad, nrm_stream_t stream);
 
 /* ---- embedding front end: reference models/user_invariant_interest_model.py:50-71,74-79 (slice_x,
  * feature_embedding, time_embedding).  x: [nrows, xcols] packed rows (tool/process_data.py:198-240), fp64

@@ -238,6 +238,14 @@ int nrm_adam_step(float* p, float* g, float* m, float* v, long n, float lr, floa
 }
 
 
+int nrm_adam_step_dev(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, float* state, int zero_grad, nrm_stream_t stream) {
+    if (!p || !g || !m || !v || !state) return fail(NRM_EINVAL, "nrm_adam_step_dev: null pointer");
+    if (n < 0 || n % 4 || !al16(p) || !al16(g) || !al16(m) || !al16(v))
+        return fail(NRM_EINVAL, "nrm_adam_step_dev: n=%ld (n %% 4 == 0, 16-byte aligned buffers)", n);
+    return check_hip(nrm::adam_dev_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, state, zero_grad, (hipStream_t)stream), "adam_dev");
+}
+
 // ------------------------------------------------------------------------------------------- embedding front end
 static int check_fe(const char* fn, int nrows, int xcols, int P, int n_sub, int behaviour, int e0, int e1, int e2, int e3) {
     if (nrows < 0 || P <= 0 || n_sub < 0 || e0 <= 0 || e1 <= 0 || e2 <= 0 || e3 <= 0)

@@ -200,14 +200,58 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     }
 }
 
+// state = {step, 1 - b1^step, sqrt(1 - b2^step)} kept on the device so that a captured hipGraph replays
+// with the right bias correction (no host-side step counter inside the graph)
+__global__ void adam_prep_kernel(float* __restrict__ state, float b1, float b2) {
+    const float step = state[0] + 1.0f;
+    state[0] = step;
+    state[1] = 1.0f - powf(b1, step);
+    state[2] = sqrtf(1.0f - powf(b2, step));
+}
+
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, long n, float lr, float b1, float b2,
+                                                       float eps, float wd, const float* __restrict__ state, int zero_grad) {
+    const float bc1 = state[1], bc2_sqrt = state[2];
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i], gv = reinterpret_cast<f32x4*>(g)[i];
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gg = fmaf(wd, pv[e], gv[e]);
+            mv[e] = fmaf(b1, mv[e], (1.0f - b1) * gg);
+            vv[e] = fmaf(b2, vv[e], (1.0f - b2) * gg * gg);
+            const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+            pv[e] -= (lr / bc1) * (mv[e] / denom);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+        if (zero_grad) reinterpret_cast<f32x4*>(g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+static unsigned adam_blocks(long n) {
+    long blocks = ((n >> 2) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
 hipError_t adam_launch(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                        float wd, int step, int zero_grad, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     const float bc1 = 1.0f - powf(b1, (float)step), bc2s = sqrtf(1.0f - powf(b2, (float)step));
-    long blocks = ((n >> 2) + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, zero_grad);
+    hipLaunchKernelGGL(adam_kernel, dim3(adam_blocks(n)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, zero_grad);
+    return hipGetLastError();
+}
+
+hipError_t adam_dev_launch(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                           float wd, float* state, int zero_grad, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, st, state, b1, b2);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(adam_blocks(n)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, state, zero_grad);
     return hipGetLastError();
 }
 

@@ -11,4 +11,6 @@ hipError_t loss_launch(const float* out, const float* label, const long* uid, co
                        int B, int T, float* loss_sum, float* dout, float* ddelta, hipStream_t st);
 hipError_t adam_launch(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                        float wd, int step, int zero_grad, hipStream_t st);
+hipError_t adam_dev_launch(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                           float wd, float* state, int zero_grad, hipStream_t st);
 }  // namespace nrm

@@ -176,3 +176,26 @@ def test_frontend_flags_out_of_range_index_like_indexerror(lib):
     with pytest.raises(IndexError):
         ops.check_index_errors("cuda")
     ops.check_index_errors("cuda")                          # flag is cleared after raising
+
+
+def test_graphed_train_step_replays_like_eager(lib):
+    """trainer.GraphedTrainStep: the whole step (forward, loss, backward, Adam+zero_grad) captured in one HIP graph;
+    three replays must land where three eager steps land (same kernels, float-atomic order noise only)."""
+    from news_recommendation_model_amd import trainer
+    case, eager, tb, batch, fx = _model_and_batch("tiny_train")
+    graphed = _model_and_batch("tiny_train")[1]
+    eager.train(); graphed.train()
+    eopt, gopt = trainer.FlatAdam(eager), trainer.FlatAdam(graphed)
+    for _ in range(3 + 3):                                   # GraphedTrainStep runs 3 eager warm-up steps itself
+        le, _ = trainer.train_step(eager, eopt, tb)
+    step = trainer.GraphedTrainStep(graphed, gopt, tb, warmup=3)
+    losses = []
+    for _ in range(3):
+        lg, out = step.replay()
+        losses.append(float(lg))
+    torch.cuda.synchronize()
+    assert gopt.steps == eopt.steps == 6                     # 3 warm-up steps + 3 replays (the capture does not execute)
+    assert abs(losses[-1] - float(le)) < 1e-4 * abs(float(le))
+    assert losses[0] > losses[-1]                            # it is really training
+    for (k, a), (_, b) in zip(eager.named_parameters(), graphed.named_parameters()):
+        assert torch.allclose(a, b, rtol=0, atol=5e-4), k
