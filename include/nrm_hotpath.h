@@ -137,6 +137,12 @@ int nrm_frontend_bwd(const void* x, int x_is_f64, int nrows, int xcols, int P, i
                      float* d_cat_tab, float* d_sen_w, float* d_sen_b, float* d_type_tab,
                      float* d_year_tab, float* d_month_tab, float* d_day_tab, float* d_hour_tab, nrm_stream_t stream);
 
+/* ---- per-impression ROC-AUC and top-1 hit (reference train.py:77-80, verify.py:25-36, tool/evaluation.py:3-5;
+ * sklearn roc_auc_score for binary labels = Mann-Whitney U with ties counted 1/2).  score, label [B,T]; len [B]
+ * (int32, candidates that count per row, NULL = T).  auc[b] = -1 where a row holds a single class. */
+int nrm_row_auc(const float* score, const float* label, const int* len, int B, int T, float* auc, int* top1,
+                nrm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

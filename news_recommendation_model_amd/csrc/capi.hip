@@ -246,6 +246,13 @@ int nrm_adam_step_dev(float* p, float* g, float* m, float* v, long n, float lr, 
     return check_hip(nrm::adam_dev_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, state, zero_grad, (hipStream_t)stream), "adam_dev");
 }
 
+int nrm_row_auc(const float* score, const float* label, const int* len, int B, int T, float* auc, int* top1,
+                nrm_stream_t stream) {
+    if (!score || !label || !auc || !top1) return fail(NRM_EINVAL, "nrm_row_auc: null pointer");
+    if (B < 0 || T <= 0) return fail(NRM_EINVAL, "nrm_row_auc: B=%d T=%d", B, T);
+    return check_hip(nrm::row_auc_launch(score, label, len, B, T, auc, top1, (hipStream_t)stream), "row_auc");
+}
+
 // ------------------------------------------------------------------------------------------- embedding front end
 static int check_fe(const char* fn, int nrows, int xcols, int P, int n_sub, int behaviour, int e0, int e1, int e2, int e3) {
     if (nrows < 0 || P <= 0 || n_sub < 0 || e0 <= 0 || e1 <= 0 || e2 <= 0 || e3 <= 0)

@@ -255,4 +255,56 @@ hipError_t adam_dev_launch(float* p, float* g, float* m, float* v, long n, float
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// per-impression ROC-AUC and top-1 hit (reference train.py:77-80, verify.py:25-36, tool/evaluation.py:3-5):
+// AUC = (#{pos i, neg j: s_i > s_j} + 0.5 #{s_i == s_j}) / (n_pos n_neg)  -- the Mann-Whitney form sklearn's
+// roc_auc_score evaluates for binary labels.  One wave per impression, lane = candidate (T <= 256); only the
+// first len[b] candidates count (trailing padding).  auc = -1 where only one class is present (sklearn raises).
+__global__ __launch_bounds__(256) void row_auc_kernel(const float* __restrict__ score, const float* __restrict__ label,
+                                                      const int* __restrict__ len, int B, int T,
+                                                      float* __restrict__ auc, int* __restrict__ top1) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int n = len ? min(len[b], T) : T;
+    const float* s = score + (long)b * T;
+    const float* y = label + (long)b * T;
+    float gt = 0.f, eq = 0.f, npos = 0.f;
+    float best_s = -3.0e38f, best_y = -3.0e38f;
+    int arg_s = 0x7fffffff, arg_y = 0x7fffffff;
+    for (int i = lane; i < n; i += 64) {
+        const float si = s[i], yi = y[i];
+        if (si > best_s) { best_s = si; arg_s = i; }
+        if (yi > best_y) { best_y = yi; arg_y = i; }
+        if (yi > 0.5f) {
+            npos += 1.f;
+            for (int j = 0; j < n; ++j) {
+                if (y[j] <= 0.5f) { gt += si > s[j] ? 1.f : 0.f; eq += si == s[j] ? 1.f : 0.f; }
+            }
+        }
+    }
+    gt = wave_sum64(gt); eq = wave_sum64(eq); npos = wave_sum64(npos);
+    // argmax with first-index tie-break (numpy.argmax)
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float os = __shfl_xor(best_s, o), oy = __shfl_xor(best_y, o);
+        const int oas = __shfl_xor(arg_s, o), oay = __shfl_xor(arg_y, o);
+        if (os > best_s || (os == best_s && oas < arg_s)) { best_s = os; arg_s = oas; }
+        if (oy > best_y || (oy == best_y && oay < arg_y)) { best_y = oy; arg_y = oay; }
+    }
+    if (lane == 0) {
+        const float nneg = (float)n - npos;
+        auc[b] = (npos > 0.f && nneg > 0.f) ? (gt + 0.5f * eq) / (npos * nneg) : -1.0f;
+        top1[b] = (n > 0 && arg_s == arg_y) ? 1 : 0;
+    }
+}
+
+hipError_t row_auc_launch(const float* score, const float* label, const int* len, int B, int T, float* auc, int* top1,
+                          hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(row_auc_kernel, dim3((B + 3) / 4), dim3(256), 0, st, score, label, len, B, T, auc, top1);
+    return hipGetLastError();
+}
+
 }  // namespace nrm

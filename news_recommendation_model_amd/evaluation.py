@@ -1,0 +1,98 @@
+"""Inference and validation semantics of the reference's test.py / verify.py on top of the HIP forward.
+
+  predict(models, batch)        test.py:31-74  model_test: eval-mode forward, trailing padding common to the batch
+                                trimmed before the forward (:48-56), softmax over candidates averaged over the
+                                model list (:58-64), and -- for rows that still carry their own padding -- a SECOND
+                                softmax over the already-softmaxed, de-padded slice (:68).  Kept as is, not "fixed".
+  row_auc_top1(scores, labels)  train.py:77-80 / verify.py:25-36: per-impression ROC-AUC and top-1 hit, on device
+                                (C ABI nrm_row_auc) instead of one sklearn call per row on the host.
+  validate(models, batches)     verify.py:19-43 model_validation: [mean AUC, top-1 rate].
+  rank_row(scores)              test.py:118-126: 1-based rank of every candidate, highest score first.
+  save_checkpoint / load_checkpoint   train.py:95-97 (state_dict minus 'delta'), test.py:160 (strict=False).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import native, ops
+
+
+@torch.no_grad()
+def predict(models, batch):
+    """-> (scores [B, T'] on device, live [B] number of real candidates per row).  ``batch`` holds x_history,
+    x_target, x_global and empty_num (trailing all-padding candidates per row)."""
+    xh, xt, xg = batch["x_history"], batch["x_target"], batch["x_global"]
+    ops._require_gpu(xh, xt, xg)
+    empty = batch["empty_num"].to(xt.device).to(torch.int64)
+    trim = int(empty.min()) if empty.numel() else 0
+    if trim > 0:                                              # test.py:48-56
+        xt, xg = xt[:, :-trim], xg[:, :-trim]
+        empty = empty - trim
+    out = None
+    for m in models:                                          # test.py:58-64
+        m.eval()
+        p = torch.softmax(m(xh, xt, xg), dim=1)
+        out = p if out is None else out + p
+    out = out / len(models)
+    T = out.shape[1]
+    live = T - empty
+    # rows with remaining padding: softmax AGAIN over the de-padded slice of the softmaxed scores (test.py:68)
+    cols = torch.arange(T, device=out.device)[None, :]
+    mask = cols < live[:, None]
+    padded = (empty > 0)[:, None]
+    again = torch.softmax(out.masked_fill(~mask, float("-inf")), dim=1)
+    scores = torch.where(padded, again, out)
+    return scores, live
+
+
+def row_auc_top1(scores, labels, live=None):
+    """Per-row AUC [B] (fp32, -1 where a row has one class) and top-1 hit [B] (int32) on the device."""
+    ops._require_gpu(scores, labels)
+    s = scores.to(torch.float32).contiguous()
+    y = labels.to(torch.float32).contiguous()
+    B, T = s.shape
+    ln = live.to(torch.int32).contiguous() if live is not None else None
+    auc = torch.empty(B, dtype=torch.float32, device=s.device)
+    top1 = torch.empty(B, dtype=torch.int32, device=s.device)
+    native.call("nrm_row_auc", native.ptr(s), native.ptr(y), native.ptr(ln) if ln is not None else None, B, T,
+                native.ptr(auc), native.ptr(top1), native.stream_ptr())
+    return auc, top1
+
+
+@torch.no_grad()
+def validate(models, batches):
+    """verify.py:19-43: mean per-impression AUC and top-1 rate over an iterable of device batches (with labels)."""
+    auc_sum = torch.zeros((), dtype=torch.float64, device="cuda")
+    hit_sum = torch.zeros((), dtype=torch.float64, device="cuda")
+    n = 0
+    for batch in batches:
+        scores, live = predict(models, batch)
+        label = batch["label"][:, :scores.shape[1]].to(scores.device)
+        auc, top1 = row_auc_top1(scores, label, live)
+        if bool((auc < 0).any()):
+            raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
+        auc_sum += auc.double().sum()
+        hit_sum += top1.double().sum()
+        n += scores.shape[0]
+    return [float(auc_sum / n), float(hit_sum / n)]
+
+
+def rank_row(scores_row):
+    """test.py:118-126: rank string items -- candidate with the highest score gets rank 1 (stable for ties)."""
+    order = sorted(range(len(scores_row)), key=lambda i: scores_row[i], reverse=True)
+    rank = [0] * len(scores_row)
+    for r, i in enumerate(order):
+        rank[i] = r + 1
+    return rank
+
+
+def save_checkpoint(model, path):
+    """train.py:95-97: the state_dict without the per-user bias ``delta``."""
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if k != "delta"}
+    torch.save(sd, path)
+
+
+def load_checkpoint(model, path):
+    """test.py:160: load_state_dict(strict=False); only tensors are read from the file (weights_only)."""
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    return model.load_state_dict(sd, strict=False)

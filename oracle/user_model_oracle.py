@@ -217,3 +217,33 @@ def row_auc(label_row, score_row):
 
 def batch_auc(label, score):
     return np.array([row_auc(label[b], score[b]) for b in range(label.shape[0])])
+
+
+# --------------------------------------------------------------------------- inference (test.py:31-74)
+def model_test_scores(param_list, batch):
+    """Restatement of reference test.py:31-74 ``model_test`` for one batch: eval-mode forward of every model,
+    trailing padding common to the batch trimmed first (:48-56), softmax over candidates averaged over the models
+    (:58-64), then per row either the scores as they are or -- when the row still has padding -- a second softmax
+    over the de-padded slice (:66-70).  Returns a list of 1-D arrays (one per impression).
+    PARITY UNPINNED for this function: test.py cannot be imported here (it imports tool.process_data, which needs
+    the absent ``zstandard`` package) and the reference holds no fixture for it; it is restated from the source text."""
+    xh, xt, xg = batch["x_history"], batch["x_target"], batch["x_global"]
+    empty = batch["empty_num"].clone()
+    trim = int(empty.min())
+    if trim > 0:
+        xt, xg = xt[:, :-trim], xg[:, :-trim]
+        empty = empty - trim
+    out = None
+    with torch.no_grad():
+        for p in param_list:
+            pr = torch.softmax(user_model_forward(p, xh, xt, xg, training=False), dim=1)
+            out = pr if out is None else out + pr
+        out = out / len(param_list)
+        rows = []
+        for i in range(out.shape[0]):
+            z = int(empty[i])
+            if z > 0:
+                rows.append(torch.softmax(out[i:i + 1, 0:-z], dim=1).squeeze(0).numpy())
+            else:
+                rows.append(out[i].numpy())
+    return rows
