@@ -207,11 +207,22 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
         }
     };
 
-    // one sub-pass of group g over d tiles [J0, J0+NJ).  On entry set 0 holds step 0.  After its last MFMA
-    // batch it prefetches step 0 of the following sub-pass (tiles [NJ0, NJ0+NNJ) of group gn) into set 0,
-    // so that latency hides under the epilogue.
+    // one sub-pass of group g over d tiles [J0, J0+NJ).  On entry sets 0 and 1 hold steps 0 and 1.  After its
+    // last MFMA batch it prefetches steps 0 and 1 of the following sub-pass (tiles [NJ0, NJ0+NNJ) of group gn):
+    // their latency hides under the epilogue, and -- vmcnt retires in issue order -- the first load issued AFTER
+    // this group's float atomics is then only needed two MFMA batches later.
     auto sub_pass = [&](auto j0c, auto njc, auto nj0c, auto nnjc, int g, int gn, bool first_of_group) {
         constexpr int J0 = decltype(j0c)::value, NJ = decltype(njc)::value;
+        // scale rows of this group for the dW_p update: loaded here, consumed in the epilogue
+        float sr[NJ];
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) {
+            sr[jt] = 0.f;
+            if (WITH_DW) {
+                const int d = d0 + 16 * (J0 + jt) + r16;
+                sr[jt] = p.srow[(long)g * p.lds_ + (EXACT || d < D ? d : 0)];
+            }
+        }
         f32x4 E[KT][NJ];
 #pragma unroll
         for (int it = 0; it < KT; ++it)
@@ -225,34 +236,30 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
                 for (int jt = 0; jt < NJ; ++jt) E[it][jt] = mfma16(a[it], b[jt], E[it][jt]);
         };
         for (int s = 0; s < nsteps; s += 2) {
-            if (s + 1 < nsteps) load_step(j0c, njc, a1, b1, s + 1);
             mfma_batch(a0, b0);
+            if (s + 2 < nsteps) load_step(j0c, njc, a0, b0, s + 2);
             if (s + 1 < nsteps) {
-                if (s + 2 < nsteps) load_step(j0c, njc, a0, b0, s + 2);
                 mfma_batch(a1, b1);
+                if (s + 3 < nsteps) load_step(j0c, njc, a1, b1, s + 3);
             }
         }
         if (gn < g_hi) {
             if (gn != g) open_group(gn);
             load_step(nj0c, nnjc, a0, b0, 0);
+            if (nsteps > 1) load_step(nj0c, nnjc, a1, b1, 1);
         }
 
         // epilogue: lane holds E[k = k0+16it+4q+e][d = d0+16jt+r16]
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) {
             const int dl = 16 * (J0 + jt) + r16;
-            float sr = 0.f;
-            if (WITH_DW) {
-                const int d = d0 + dl;
-                sr = p.srow[(long)g * p.lds_ + (EXACT || d < D ? d : 0)];
-            }
             float acc = 0.f;
 #pragma unroll
             for (int it = 0; it < KT; ++it) {
                 const f32x4 w4 = *reinterpret_cast<const f32x4*>(&wpt[dl * LDK + 16 * it + 4 * q]);
                 const f32x4 e4 = E[it][jt];
                 acc = fmaf(w4[0], e4[0], fmaf(w4[1], e4[1], fmaf(w4[2], e4[2], fmaf(w4[3], e4[3], acc))));
-                if (WITH_DW) dW[it][J0 + jt] += e4 * sr;
+                if (WITH_DW) dW[it][J0 + jt] += e4 * sr[jt];
             }
             acc += __shfl_xor(acc, 16);
             acc += __shfl_xor(acc, 32);
@@ -264,6 +271,7 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
     if (g_lo < g_hi) {
         open_group(g_lo);
         load_step(IC<0>{}, IC<KS>{}, a0, b0, 0);
+        if (nsteps > 1) load_step(IC<0>{}, IC<KS>{}, a1, b1, 1);
     }
     for (int g = g_lo; g < g_hi; ++g) {
         if constexpr (KS == DT) {
