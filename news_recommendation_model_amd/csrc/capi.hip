@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/nrm_hotpath.h"
 #include "pwattn.hpp"
@@ -24,8 +25,14 @@ static int check_hip(hipError_t e, const char* what) {
     return fail(NRM_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
 }
 
-// waves the E-form kernels aim to keep in flight: 256 CUs x 4 SIMDs x 2 waves
+// wave slots of the chip at 2 waves/SIMD: 256 CUs x 4 SIMDs x 2
 static const int kTargetWaves = 2048;
+// Wave tasks of the two backward contraction launches.  Measured on MI355X at C3 (scripts/sweep_waves.sh): several
+// rounds of smaller tasks balance better than exactly one round (dh pass 4.81 -> 4.58 ms at 4 rounds of 3 waves/SIMD,
+// dt/dW pass 5.81 -> 5.56 ms at 3 rounds; every split of the dW pass costs one [D,D] partial slab).
+// NRM_BT_WAVES / NRM_BH_WAVES override them for tuning.
+static const int kBtWaves = 6144;
+static const int kBhWaves = 12288;
 
 static int check_dims(const char* fn, int B, int T, int H, int D) {
     if (B < 0 || T <= 0 || H <= 0 || D <= 0) return fail(NRM_EINVAL, "%s: B=%d T=%d H=%d D=%d must be positive", fn, B, T, H, D);
@@ -84,7 +91,9 @@ int nrm_pwattn_bwd_dz(float* z_inout, const float* ds, const float* w2, float* d
 
 int nrm_pwattn_bwd_nsplit(int B, int T, int H, int D) {
     if (B <= 0 || T <= 0 || H <= 0 || D <= 0) return 0;
-    return nrm::bwd_e_plan(D, B * T, kTargetWaves).nsplit;
+    int tw1 = kBtWaves;
+    if (const char* e = getenv("NRM_BT_WAVES")) tw1 = atoi(e);
+    return nrm::bwd_e_plan(D, B * T, tw1).nsplit;
 }
 
 int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, const float* wp, int ldwp,
@@ -103,7 +112,9 @@ int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, con
         p.Y = h; p.ys1 = HD; p.yrs = D;
         p.wp = wp; p.ldwp = ldwp; p.srow = t; p.lds_ = D; p.out = dt; p.ldo = D; p.ws = ws;
         p.G = B * T; p.G2 = T; p.R = H; p.D = D;
-        const nrm::BwdEPlan pl = nrm::bwd_e_plan(D, p.G, kTargetWaves);
+        int tw1 = kBtWaves;
+        if (const char* e = getenv("NRM_BT_WAVES")) tw1 = atoi(e);
+        const nrm::BwdEPlan pl = nrm::bwd_e_plan(D, p.G, tw1);
         if (int rc = check_hip(nrm::bwd_e_launch(p, pl, true, (hipStream_t)stream), "bwd_e pass 1")) return rc;
     }
     // pass 2: groups (b,h); rows r = t.  X_g = dz[b,:,h,:], Y_g = t[b];  out = dh
@@ -114,7 +125,9 @@ int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, con
         p.wp = wp; p.ldwp = ldwp; p.srow = nullptr; p.lds_ = 0; p.out = dh; p.ldo = D; p.ws = nullptr;
         p.G = B * H; p.G2 = H; p.R = T; p.D = D;
         // this variant keeps no dW_p accumulators (<= 168 VGPRs): three waves per SIMD
-        const nrm::BwdEPlan pl = nrm::bwd_e_plan(D, p.G, kTargetWaves * 3 / 2);
+        int tw = kBhWaves;
+        if (const char* e = getenv("NRM_BH_WAVES")) tw = atoi(e);
+        const nrm::BwdEPlan pl = nrm::bwd_e_plan(D, p.G, tw);
         if (int rc = check_hip(nrm::bwd_e_launch(p, pl, false, (hipStream_t)stream), "bwd_e pass 2")) return rc;
     }
     return NRM_OK;

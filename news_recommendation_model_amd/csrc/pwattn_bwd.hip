@@ -317,8 +317,9 @@ BwdEPlan bwd_e_plan(int D, int G, int target_waves) {
     pl.ndcol = (n16 + pl.DT - 1) / pl.DT;
     pl.nkw = (n16 + pl.KT - 1) / pl.KT;
     const int tiles = pl.ndcol * pl.nkw;
-    // exactly ONE round of wave tasks: tiles * nsplit <= target_waves, nsplit a multiple of 4 (4 splits per
-    // workgroup).  One task more than the machine holds would add a whole second round.
+    // tiles * nsplit <= target_waves, nsplit a multiple of 4 (4 splits per workgroup).  target_waves is either
+    // at most the number of resident wave slots (ONE round: one task more would add a whole second round) or
+    // several times it (many small tasks, dynamically balanced) -- see capi.hip.
     int ns = target_waves / tiles / 4 * 4;
     if (ns < 4) ns = 4;
     if (ns > G) ns = G > 0 ? G : 1;
