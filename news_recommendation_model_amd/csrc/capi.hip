@@ -33,6 +33,7 @@ static const int kTargetWaves = 2048;
 // NRM_BT_WAVES / NRM_BH_WAVES override them for tuning.
 static const int kBtWaves = 6144;
 static const int kBhWaves = 12288;
+static const int kTnWaves = 4096;      // gemm_tn (dW = dY^T X): NRM_TN_WAVES overrides
 
 static int check_dims(const char* fn, int B, int T, int H, int D) {
     if (B < 0 || T <= 0 || H <= 0 || D <= 0) return fail(NRM_EINVAL, "%s: B=%d T=%d H=%d D=%d must be positive", fn, B, T, H, D);
@@ -170,9 +171,14 @@ int nrm_gemm_nt(const float* x, int ldx, int M, const float* packed, int N, int 
     return check_hip(nrm::gemm_nt_launch(p, pl, epilogue, (hipStream_t)stream), "gemm_nt");
 }
 
+static int tn_waves() {
+    if (const char* e = getenv("NRM_TN_WAVES")) return atoi(e);
+    return kTnWaves;
+}
+
 int nrm_gemm_tn_nsplit(int ncols_i, int ncols_j, int R) {
     if (ncols_i <= 0 || ncols_j <= 0 || R <= 0) return 0;
-    return nrm::gemm_tn_plan(ncols_i, ncols_j, R, kTargetWaves).nsplit;
+    return nrm::gemm_tn_plan(ncols_i, ncols_j, R, tn_waves()).nsplit;
 }
 
 int nrm_gemm_tn(const float* A, int lda, int ncols_i, const float* B, int ldb, int ncols_j, int R,
@@ -181,7 +187,7 @@ int nrm_gemm_tn(const float* A, int lda, int ncols_i, const float* B, int ldb, i
     if (ncols_i <= 0 || ncols_j <= 0 || R <= 0 || lda < ncols_i || ldb < ncols_j)
         return fail(NRM_EINVAL, "nrm_gemm_tn: ncols_i=%d ncols_j=%d R=%d lda=%d ldb=%d", ncols_i, ncols_j, R, lda, ldb);
     if (ldws % 4 || ldws < ncols_i || !al16(ws)) return fail(NRM_EINVAL, "nrm_gemm_tn: ldws=%d", ldws);
-    const nrm::GemmTnPlan pl = nrm::gemm_tn_plan(ncols_i, ncols_j, R, kTargetWaves);
+    const nrm::GemmTnPlan pl = nrm::gemm_tn_plan(ncols_i, ncols_j, R, tn_waves());
     if ((long)pl.rps * (lda > ldb ? lda : ldb) * 4 >= (1L << 31)) return fail(NRM_EINVAL, "nrm_gemm_tn: split too large");
     nrm::GemmTnParams p = {};
     p.A = A; p.lda = lda; p.acols = lda; p.B = B; p.ldb = ldb; p.bcols = ldb;

@@ -210,17 +210,19 @@ __global__ __launch_bounds__(256, 2) void pwattn_fwd_kernel(const FwdParams p) {
 // ---------------------------------------------------------------------------------------------
 // host-side dispatch (called from capi.hip)
 
-// Tile table: NT 16-column tiles per N-chunk x MT 16-row tiles per wave.  4*NT*MT accumulator
-// registers must leave room for the staging prefetch at 2 waves/SIMD (<= 256 VGPRs, no scratch).
-static const int kNT[8] = {4, 6, 8, 10, 12, 13, 14, 16};
-static const int kMT[8] = {4, 4, 3, 3, 3, 3, 2, 2};     // also bounded by LDS: 2 workgroups x 2 buffers <= 160 KB
+// Tile table: NT 16-column tiles per N-chunk x MT 16-row tiles per wave.  4*NT*MT accumulator registers must
+// stay within 2 waves/SIMD (<= 256 VGPRs), and 2 workgroups x 2 LDS buffers within 160 KB.
+// Up to 25 column tiles (D <= 400) the whole width is ONE N-chunk: no column padding and a single
+// accumulator-init / epilogue per row tile (measured at D=400: 13x3 in two chunks 4.73 ms, 25x1 4.28 ms).
+static const int kNT[10] = {4, 6, 8, 10, 12, 13, 14, 16, 20, 25};
+static const int kMT[10] = {4, 4, 3, 3, 3, 3, 2, 2, 1, 1};
 
 FwdPlan pwattn_fwd_plan(int D) {
     const int n16 = (D + 15) / 16;
-    const int nch = (n16 + 15) / 16;               // at most 16 tiles of 16 columns per N-chunk
+    const int nch = n16 <= 25 ? 1 : (n16 + 15) / 16;    // wider than 25 tiles: chunks of at most 16 tiles
     const int need = (n16 + nch - 1) / nch;
-    int sel = 7;
-    for (int i = 0; i < 8; ++i) if (kNT[i] >= need) { sel = i; break; }
+    int sel = 9;
+    for (int i = 0; i < 10; ++i) if (kNT[i] >= need) { sel = i; break; }
     FwdPlan pl;
     pl.NT = kNT[sel]; pl.MT = kMT[sel]; pl.nchunks = nch;
     pl.rows = nch * pl.NT * 16; pl.kchunks = n16;
@@ -248,6 +250,8 @@ hipError_t pwattn_fwd_launch(const FwdParams& p, const FwdPlan& pl, hipStream_t 
         case 13: return launch_fwd_t<13, 3>(p, st);
         case 14: return launch_fwd_t<14, 2>(p, st);
         case 16: return launch_fwd_t<16, 2>(p, st);
+        case 20: return launch_fwd_t<20, 1>(p, st);
+        case 25: return launch_fwd_t<25, 1>(p, st);
     }
     return hipErrorInvalidValue;
 }
