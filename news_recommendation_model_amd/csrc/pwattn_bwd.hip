@@ -333,7 +333,7 @@ static hipError_t launch_e_t(BwdEParams p, const BwdEPlan& pl, bool with_dw, hip
     p.nkw = pl.nkw; p.ndcol = pl.ndcol; p.gps = pl.gps; p.nsplit = pl.nsplit;
     const dim3 grid(pl.nkw * pl.ndcol, (pl.nsplit + 3) / 4), block(256);
     const bool exact = p.D % (16 * KT) == 0 && p.D % (16 * DT) == 0;
-    constexpr int KS_DW = (DT * KT > 16) ? (DT + 1) / 2 : DT;     // 5x5 with dW: sub-passes of 3 + 2 d-tiles
+    constexpr int KS_DW = DT;     // single pass (40 B of scratch at 5x5); the 3+2 sub-pass split is KS_DW = (DT + 1) / 2
     if (with_dw) {
         if (exact) hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, true>), grid, block, 0, st, p);
         else       hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, false>), grid, block, 0, st, p);
