@@ -51,6 +51,16 @@ __device__ __forceinline__ float wave_sum16(float v) {   // sum over the 16 lane
     return v;
 }
 
+// sum over the four 16-lane rows (lanes l, l^16, l^32, l^48) with the gfx950 row-swap instructions: two VALU ops
+// per step instead of an LDS-crossbar ds_bpermute.  v_permlane16_swap exchanges rows 1<->0' and 3<->2' of its
+// two operands, v_permlane32_swap the upper and lower halves.
+__device__ __forceinline__ float sum_rows4(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 __device__ __forceinline__ float wave_sum64(float v) {
     v = wave_sum16(v);
     v += __shfl_xor(v, 16);

@@ -274,9 +274,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTnParams p) {
     if (p.colsum && tj == 0) {
 #pragma unroll
         for (int it = 0; it < KT; ++it) {
-            float v = cs[it];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
+            const float v = sum_rows4(cs[it]);
             const int i = i0 + 16 * it + r16;
             if (q == 0 && i < p.ldws) p.colsum[(size_t)split * p.ldws + i] = v;
         }

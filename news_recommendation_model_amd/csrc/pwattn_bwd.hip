@@ -261,8 +261,7 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
                 acc = fmaf(w4[0], e4[0], fmaf(w4[1], e4[1], fmaf(w4[2], e4[2], fmaf(w4[3], e4[3], acc))));
                 if (WITH_DW) dW[it][J0 + jt] += e4 * sr[jt];
             }
-            acc += __shfl_xor(acc, 16);
-            acc += __shfl_xor(acc, 32);
+            acc = sum_rows4(acc);
             if (q == 0) bounce[dl] = acc;
         }
         (void)first_of_group;

@@ -198,9 +198,7 @@ __global__ __launch_bounds__(256, 2) void pwattn_fwd_kernel(const FwdParams p) {
     const float b2 = p.b2[0];
 #pragma unroll
     for (int jt = 0; jt < MT; ++jt) {
-        float v = s_part[jt];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
+        const float v = sum_rows4(s_part[jt]);
         const int m = m0 + (wave * MT + jt) * 16 + r16;
         if (q == 0 && m < M) p.s[m] = v + b2;
     }
