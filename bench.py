@@ -108,6 +108,29 @@ def cpu_baseline(dims, wl, seconds, cpu_batch):
                       f"{n} steps after 1 warm-up, torch CPU fp32 {cores} threads"}
 
 
+def fwd_auc_parity(dev):
+    """The 'fwd AUC parity' half of the headline metric: forward of the C3-shaped golden case (B=2, H=50, T=30,
+    D=400; outputs of the REFERENCE model, tests/golden/c3_large.npz) through the HIP path; max relative error of
+    the logits and max |AUC difference| per impression against the fixture."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        from golden_util import load_case
+        from news_recommendation_model_amd import evaluation, trainer
+        case, dims, batch, sd, fx = load_case("c3_large")
+        model = trainer.build_model(dims, int(batch["user_num"]), sd, device=dev).train()
+        tb = trainer.batch_to_device(batch, dev)
+        with torch.no_grad():
+            out = model(tb["x_history"], tb["x_target"], tb["x_global"])
+        auc, _ = evaluation.row_auc_top1(out, tb["label"])
+        r = out.cpu().numpy()
+        return {"case": "c3_large (reference fixture)", "logit_max_rel_err": float(np.abs(r - fx["r"]).max() / np.abs(fx["r"]).max()),
+                "auc_max_abs_diff": float(np.abs(auc.cpu().numpy() - fx["auc"]).max())}
+    except Exception as e:                      # never let the parity probe break the throughput line
+        return {"error": repr(e)}
+    finally:
+        sys.path.pop(0)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -236,6 +259,7 @@ def main():
             "kernels": {k: {"launches": v["launches"], "mean_ms": round(v["mean_ms"], 4)} for k, v in kern.items()},
             "grad_allreduce_bytes": opt.nbytes if world > 1 else 0, "replicas_in_sync": replicas_in_sync,
         }
+        line["fwd_auc_parity"] = fwd_auc_parity(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(dims, wl, args.cpu_seconds, args.cpu_batch)
         print(json.dumps(line), flush=True)
