@@ -96,8 +96,21 @@ class _PointwiseAttentionScores(torch.autograd.Function):
 
 
 def pointwise_attention_scores(target, history, fc1_weight, fc1_bias, fc2_weight, fc2_bias):
-    """[B,T,D] x [B,H,D] -> [B,T,H] scores (fp32)."""
-    return _PointwiseAttentionScores.apply(target, history, fc1_weight, fc1_bias, fc2_weight, fc2_bias)
+    """[B,T,D] x [B,H,D] -> [B,T,H] scores (fp32).
+
+    The kernels need the feature width to be a multiple of 4 (float4 rows).  Any other D is zero-padded here with
+    differentiable ops: padded features contribute exactly 0 to every term (their fc1 rows/columns and fc2 weights
+    are 0, gelu(0) = 0), and autograd slices the gradients back."""
+    D = target.shape[-1]
+    if D % 4 == 0:
+        return _PointwiseAttentionScores.apply(target, history, fc1_weight, fc1_bias, fc2_weight, fc2_bias)
+    _require_gpu(target, history, fc1_weight)
+    P = _pad4(D) - D
+    pad = torch.nn.functional.pad
+    blocks = [pad(fc1_weight[:, i * D:(i + 1) * D], (0, P, 0, P)) for i in range(4)]     # [D4, D4] each
+    return _PointwiseAttentionScores.apply(pad(target.to(torch.float32), (0, P)), pad(history.to(torch.float32), (0, P)),
+                                           torch.cat(blocks, dim=1), pad(fc1_bias, (0, P)),
+                                           pad(fc2_weight.reshape(1, D), (0, P)), fc2_bias)
 
 
 # ------------------------------------------------------------------------------------------------ dense layers
@@ -283,7 +296,11 @@ class _WeightedPool(torch.autograd.Function):
 
 
 def weighted_pool(scores, history):
-    return _WeightedPool.apply(scores, history)
+    D = history.shape[-1]
+    if D % 4 == 0:
+        return _WeightedPool.apply(scores, history)
+    _require_gpu(scores, history)
+    return _WeightedPool.apply(scores, torch.nn.functional.pad(history.to(torch.float32), (0, _pad4(D) - D)))[..., :D]
 
 
 # ------------------------------------------------------------------------------------------------ loss
