@@ -16,7 +16,7 @@
 
 namespace nrm {
 
-// packed[c][row][16]: element (row, 16c + 4*(s ^ ((row>>2)&3)) + e) of the logical [nrows x ncols] matrix
+// packed[c][row][16]: element (row, 16c + 4*(s ^ swz4(row)) + e) of the logical [nrows x ncols] matrix
 // src[row*rs + col*cs], zero padded to `rows` rows / 16*kchunks columns (slot swizzle: see pwattn_fwd.hip).
 __global__ void pack_rows_kernel(const float* __restrict__ src, long rs, long cs, int nrows, int ncols,
                                  int rows, int kchunks, float* __restrict__ packed) {
@@ -26,7 +26,7 @@ __global__ void pack_rows_kernel(const float* __restrict__ src, long rs, long cs
         const long rc = i >> 4;
         const int row = (int)(rc % rows);
         const int c = (int)(rc / rows);
-        const int slot = (j >> 2) ^ ((row >> 2) & 3);
+        const int slot = (j >> 2) ^ swz4(row);
         const int col = c * 16 + 4 * slot + (j & 3);
         packed[i] = (row < nrows && col < ncols) ? src[row * rs + col * cs] : 0.0f;
     }
@@ -74,10 +74,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNtParams p) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         const int rl = (wave * MT + j) * 16 + (lane >> 2);
-        const unsigned slot = (unsigned)((lane & 3) ^ (((lane >> 2) >> 2) & 3));
+        const unsigned slot = (unsigned)((lane & 3) ^ swz4(lane >> 2));
         voff_x[j] = rl < rows_here ? (unsigned)(rl * p.ldx + 4 * slot) * 4u : OOB;
     }
-    const int rslot = 4 * (q ^ ((r16 >> 2) & 3));
+    const int rslot = 4 * (q ^ swz4(r16));
 
     f32x4 acc[NT][MT];
 #pragma unroll

@@ -14,6 +14,17 @@
 //      registers across the groups a wave walks (one partial slab per split, summed after), and an output
 //      row receives one contiguous float-atomic add per k-range (5 at D=400).
 //   The side-projection gradients (from du, dv) are plain GEMMs done by the caller.
+#include <cstdlib>
+#ifndef NRM_PIPE_SGB
+#define NRM_PIPE_SGB 1
+#endif
+// timing diagnostics only (scripts/_diag/build_diag.sh): results are WRONG with either of them set
+#ifndef NRM_DIAG_NOEPI
+#define NRM_DIAG_NOEPI 0      // pipelined dh kernel without its per-group epilogue
+#endif
+#ifndef NRM_DIAG_NOLOAD
+#define NRM_DIAG_NOLOAD 0     // pipelined dh kernel that never reloads its MFMA operands
+#endif
 #include "common.hpp"
 #include "pwattn.hpp"
 
@@ -117,7 +128,7 @@ template <int KT, int DT, int KS, bool WITH_DW, bool EXACT>
 __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-descriptor builtins: device pass only (keeps the host stub)
     static_assert(KS <= DT && DT - KS <= KS, "first sub-pass must be the larger one");
-    constexpr int LDK = KT * 16 + 4;                                   // padded row of the W_p^T tile
+    constexpr int LDK = KT * 16 + 8;      // padded row of the W_p^T tile: +8 is conflict-free under gfx950 b128 lane groups (+4 is 2-way)
     __shared__ __attribute__((aligned(16))) float smem[DT * 16 * LDK + 4 * DT * 16];
     float* wpt = smem;                                                  // [DT*16 d][LDK]  = W_p[k0+k][d0+d]
     const int tid = threadIdx.x;
@@ -224,18 +235,23 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
             }
         }
         f32x4 E[KT][NJ];
-#pragma unroll
-        for (int it = 0; it < KT; ++it)
-#pragma unroll
-            for (int jt = 0; jt < NJ; ++jt) E[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
         auto mfma_batch = [&](const float (&a)[KT], const float (&b)[KS]) {
 #pragma unroll
             for (int it = 0; it < KT; ++it)
 #pragma unroll
                 for (int jt = 0; jt < NJ; ++jt) E[it][jt] = mfma16(a[it], b[jt], E[it][jt]);
         };
-        for (int s = 0; s < nsteps; s += 2) {
+        // step 0 accumulates onto an inline-constant 0 (no accumulator clearing)
+#pragma unroll
+        for (int it = 0; it < KT; ++it)
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt) E[it][jt] = mfma16(a0[it], b0[jt], f32x4{0.f, 0.f, 0.f, 0.f});
+        if (2 < nsteps) load_step(j0c, njc, a0, b0, 2);
+        if (1 < nsteps) {
+            mfma_batch(a1, b1);
+            if (3 < nsteps) load_step(j0c, njc, a1, b1, 3);
+        }
+        for (int s = 2; s < nsteps; s += 2) {
             mfma_batch(a0, b0);
             if (s + 2 < nsteps) load_step(j0c, njc, a0, b0, s + 2);
             if (s + 1 < nsteps) {
@@ -308,6 +324,194 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// (2b) software-pipelined variant of the contraction WITHOUT dW_p (the dh pass).  The epilogue of a group
+// (LDS reads of W_p^T, FMAs, row reduction, bounce, atomics) costs several times its instruction time when it
+// runs as one serial block between two MFMA streams (DESIGN.md "stamp findings").  Here a wave keeps TWO
+// accumulator sets: while the MFMAs of group g fill one, the epilogue of group g-1 drains the other, one
+// d tile per reduction step, inside the same straight-line code -- the matrix pipe never waits for it.
+// Costs 2x accumulators (2 waves/SIMD).  Needs nsteps >= PE + 2 (the peeled steps load only from the current
+// group); the launcher falls back to bwd_e_kernel otherwise.
+template <int KT, int DT, bool EXACT>
+__global__ __launch_bounds__(256, 2) void bwd_e_pipe_kernel(const BwdEParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int PE = (DT + 1) & ~1;                                  // peeled steps (even, >= DT)
+    constexpr int LDK = KT * 16 + 8;
+    __shared__ __attribute__((aligned(16))) float smem[DT * 16 * LDK + 4 * DT * 16];
+    float* wpt = smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* bounce = smem + DT * 16 * LDK + wave * (DT * 16);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int D = p.D, R = p.R;
+
+    const int nblk = gridDim.x * gridDim.y;
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = lin & 7;
+    const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+    const int dcol = logical % p.ndcol;
+    const int kw = (logical / p.ndcol) % p.nkw;
+    const int sgrp = logical / (p.ndcol * p.nkw);
+    const int d0 = dcol * (DT * 16);
+    const int k0 = kw * (KT * 16);
+
+    for (int idx = tid; idx < KT * 16 * DT * 4; idx += 256) {
+        const int kl = idx / (DT * 4), d4 = idx - kl * (DT * 4);
+        const int k = k0 + kl, d = d0 + 4 * d4;
+        f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (k < D && d < D) w = *reinterpret_cast<const f32x4*>(p.wp + (long)k * p.ldwp + d);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wpt[(4 * d4 + e) * LDK + kl] = w[e];
+    }
+    __syncthreads();
+
+    const int split = sgrp * 4 + wave;
+    if (split >= p.nsplit) return;
+    const int g_lo = split * p.gps;
+    const int g_hi = min(p.G, g_lo + p.gps);
+    if (g_lo >= g_hi) return;
+    const int nsteps = (R + 3) >> 2;
+
+    const unsigned vx = (unsigned)((long)q * p.xrs + k0 + r16) * 4u;
+    const unsigned vy = (unsigned)((long)q * p.yrs + d0 + r16) * 4u;
+    const unsigned xbytes = (unsigned)(((long)(R - 1) * p.xrs + D) * 4);
+    const unsigned ybytes = (unsigned)(((long)(R - 1) * p.yrs + D) * 4);
+    const int xstep = (int)(p.xrs * 16), ystep = (int)(p.yrs * 16);
+    unsigned mA[EXACT ? 1 : KT], mB[EXACT ? 1 : DT];
+    if (!EXACT) {
+#pragma unroll
+        for (int it = 0; it < KT; ++it) mA[it] = k0 + 16 * it + r16 < D ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int jt = 0; jt < DT; ++jt) mB[jt] = d0 + 16 * jt + r16 < D ? 0xffffffffu : 0u;
+    }
+
+    float a0[KT], b0[DT], a1[KT], b1[DT];
+    __amdgpu_buffer_rsrc_t rx, ry, rxn, ryn;                           // current / next group
+    auto open_group = [&](int gg, __amdgpu_buffer_rsrc_t& ox, __amdgpu_buffer_rsrc_t& oy) {
+        const int g1 = gg / p.G2, g2 = gg - g1 * p.G2;
+        ox = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X + (long)g1 * p.xs1 + (long)g2 * p.xs2), 0, xbytes, 0x00020000);
+        oy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Y + (long)g1 * p.ys1), 0, ybytes, 0x00020000);
+    };
+    bool diag_first = true;
+    auto load_step = [&](__amdgpu_buffer_rsrc_t dx, __amdgpu_buffer_rsrc_t dy, float (&a)[KT], float (&b)[DT], int s) {
+        if (NRM_DIAG_NOLOAD && !(diag_first && s < 2)) return;
+#pragma unroll
+        for (int it = 0; it < KT; ++it) {
+            const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(dx, vx + 64 * it, s * xstep, 0);
+            a[it] = __uint_as_float(EXACT ? v : (v & mA[it]));
+        }
+#pragma unroll
+        for (int jt = 0; jt < DT; ++jt) {
+            const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(dy, vy + 64 * jt, s * ystep, 0);
+            b[jt] = __uint_as_float(EXACT ? v : (v & mB[jt]));
+        }
+    };
+    auto mfma_batch = [&](f32x4 (&E)[KT][DT], const float (&a)[KT], const float (&b)[DT]) {
+#pragma unroll
+        for (int it = 0; it < KT; ++it)
+#pragma unroll
+            for (int jt = 0; jt < DT; ++jt) E[it][jt] = mfma16(a[it], b[jt], E[it][jt]);
+    };
+    // epilogue slice: d tile jt of a finished accumulator set -> bounce[16*jt .. 16*jt+15]
+    auto slice = [&](const f32x4 (&E)[KT][DT], int jt) {
+        const int dl = 16 * jt + r16;
+        float acc = 0.f;
+#pragma unroll
+        for (int it = 0; it < KT; ++it) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(&wpt[dl * LDK + 16 * it + 4 * q]);
+            const f32x4 e4 = E[it][jt];
+            acc = fmaf(w4[0], e4[0], fmaf(w4[1], e4[1], fmaf(w4[2], e4[2], fmaf(w4[3], e4[3], acc))));
+        }
+        acc = sum_rows4(acc);
+        if (q == 0) bounce[dl] = acc;
+    };
+    auto flush = [&](int grow) {
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __builtin_amdgcn_wave_barrier();
+        float* orow = p.out + (long)grow * p.ldo + d0;
+#pragma unroll
+        for (int c = 0; c < DT * 16; c += 64) {
+            const int dl = c + lane;
+            if (dl < DT * 16 && (EXACT || d0 + dl < D)) atomicAdd(orow + dl, bounce[dl]);
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __builtin_amdgcn_wave_barrier();
+    };
+    // Group g into Ec while Ep (group `prow`) drains.  On entry sets 0/1 hold steps 0/1 of g and (rx, ry) is
+    // open on g; on exit they hold steps 0/1 of g+1 (if any) and (rx, ry) is open on g+1.
+    auto body = [&](f32x4 (&Ec)[KT][DT], const f32x4 (&Ep)[KT][DT], int g, int prow) {
+        const bool has_next = g + 1 < g_hi;
+        if (has_next) open_group(g + 1, rxn, ryn);
+#pragma unroll
+        for (int s = 0; s < PE; ++s) {                                  // nsteps >= PE + 2: loads stay in group g
+            if (s == 0 && !NRM_DIAG_NOEPI) {                            // C = inline 0: no accumulator clearing
+#pragma unroll
+                for (int it = 0; it < KT; ++it)
+#pragma unroll
+                    for (int jt = 0; jt < DT; ++jt) Ec[it][jt] = mfma16(a0[it], b0[jt], f32x4{0.f, 0.f, 0.f, 0.f});
+                load_step(rx, ry, a0, b0, 2);
+            }
+            else if (s & 1) { mfma_batch(Ec, a1, b1); load_step(rx, ry, a1, b1, s + 2); }
+            else            { mfma_batch(Ec, a0, b0); load_step(rx, ry, a0, b0, s + 2); }
+            if (s < DT && !NRM_DIAG_NOEPI) {
+                slice(Ep, s);
+#if NRM_PIPE_SGB
+                // place the slice in the shadow of this step's MFMAs: LDS reads + next loads in the first gaps,
+                // the FMAs / row reduction two per gap after that
+#pragma unroll
+                for (int i = 0; i < KT * DT; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i < KT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (i < KT + DT) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if (i >= KT) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                }
+#endif
+            }
+            if (s == DT - 1 && !NRM_DIAG_NOEPI) flush(prow);
+        }
+        for (int s = PE; s < nsteps; s += 2) {
+            mfma_batch(Ec, a0, b0);
+            if (s + 2 < nsteps) load_step(rx, ry, a0, b0, s + 2);
+            else if (has_next)  load_step(rxn, ryn, a0, b0, 0);
+            if (s + 1 < nsteps) {
+                mfma_batch(Ec, a1, b1);
+                if (s + 3 < nsteps) load_step(rx, ry, a1, b1, s + 3);
+                else if (has_next)  load_step(rxn, ryn, a1, b1, 1);
+            } else if (has_next) {
+                load_step(rxn, ryn, a1, b1, 1);                         // odd nsteps: set 1 is free already
+            }
+        }
+        rx = rxn; ry = ryn;
+    };
+    auto drain = [&](const f32x4 (&E)[KT][DT], int grow) {
+#pragma unroll
+        for (int jt = 0; jt < DT; ++jt) slice(E, jt);
+        flush(grow);
+    };
+
+    f32x4 E0[KT][DT], E1[KT][DT];
+#pragma unroll
+    for (int it = 0; it < KT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < DT; ++jt) E1[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};   // "group before the first": adds 0
+    open_group(g_lo, rx, ry);
+    rxn = rx; ryn = ry;
+    load_step(rx, ry, a0, b0, 0);
+    load_step(rx, ry, a1, b1, 1);
+    diag_first = false;
+    int g = g_lo;
+    int prow = g_lo;                                                    // zeros go to the split's own first row
+    for (; g + 1 < g_hi; g += 2) {
+        body(E0, E1, g, prow);
+        body(E1, E0, g + 1, g);
+        prow = g + 1;
+    }
+    if (g < g_hi) { body(E0, E1, g, prow); drain(E0, g); }
+    else          { drain(E1, g - 1); }
+#endif
+}
+
 BwdEPlan bwd_e_plan(int D, int G, int target_waves) {
     const int n16 = (D + 15) / 16;
     const int c5 = (n16 + 4) / 5 * 5, c4 = (n16 + 3) / 4 * 4;
@@ -327,6 +531,11 @@ BwdEPlan bwd_e_plan(int D, int G, int target_waves) {
     return pl;
 }
 
+static bool pipe_enabled() {
+    static const bool on = [] { const char* e = getenv("NRM_BH_PIPE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 template <int KT, int DT>
 static hipError_t launch_e_t(BwdEParams p, const BwdEPlan& pl, bool with_dw, hipStream_t st) {
     p.nkw = pl.nkw; p.ndcol = pl.ndcol; p.gps = pl.gps; p.nsplit = pl.nsplit;
@@ -336,6 +545,9 @@ static hipError_t launch_e_t(BwdEParams p, const BwdEPlan& pl, bool with_dw, hip
     if (with_dw) {
         if (exact) hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, true>), grid, block, 0, st, p);
         else       hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, false>), grid, block, 0, st, p);
+    } else if (pipe_enabled() && (p.R + 3) / 4 >= ((DT + 1) & ~1) + 2) {
+        if (exact) hipLaunchKernelGGL((bwd_e_pipe_kernel<KT, DT, true>), grid, block, 0, st, p);
+        else       hipLaunchKernelGGL((bwd_e_pipe_kernel<KT, DT, false>), grid, block, 0, st, p);
     } else {
         if (exact) hipLaunchKernelGGL((bwd_e_kernel<KT, DT, DT, false, true>), grid, block, 0, st, p);
         else       hipLaunchKernelGGL((bwd_e_kernel<KT, DT, DT, false, false>), grid, block, 0, st, p);

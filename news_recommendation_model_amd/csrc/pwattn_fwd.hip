@@ -24,7 +24,7 @@ namespace nrm {
 // W_p prepack: packed[c][row][16] = W_p[row][16c .. 16c+15], zero padded to `rows` rows and to a
 // multiple of 16 columns, so that one K-chunk of one N-chunk is a single contiguous block that LDS-DMA
 // copies verbatim.  Inside a 64-B row the four 16-B slots are XOR-swizzled (slot s holds columns
-// 4*(s ^ ((row>>2)&3)) ..+3): the unpadded LDS image is then read conflict-free with ds_read_b128.
+// 4*(s ^ swz4(row)) ..+3): the unpadded LDS image is then read conflict-free with ds_read_b128.
 // W_p = fc1.weight[:, 3D:4D] (row stride ldw = 4D).
 __global__ void pack_wp_kernel(const float* __restrict__ w, int ldw, int D, int rows, int kchunks,
                                float* __restrict__ packed) {
@@ -34,7 +34,7 @@ __global__ void pack_wp_kernel(const float* __restrict__ w, int ldw, int D, int 
         const long rc = i >> 4;
         const int row = (int)(rc % rows);
         const int c = (int)(rc / rows);
-        const int slot = (j >> 2) ^ ((row >> 2) & 3);
+        const int slot = (j >> 2) ^ swz4(row);
         const int d = c * 16 + 4 * slot + (j & 3);
         packed[i] = (row < D && d < D) ? w[(long)row * ldw + d] : 0.0f;
     }
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void pwattn_fwd_kernel(const FwdParams p) {
 
     // --- staging (LDS-DMA): a wave copies its OWN MT*16 t rows and h rows (one 1-KiB piece = 16 rows x 64 B
     // per wave-instruction, lane -> row lane>>2, 16-B slot lane&3) and every 4th 1-KiB piece of the W chunk.
-    // The source slot is XOR-swizzled with (row>>2)&3; readers apply the same XOR.
+    // The source slot is XOR-swizzled with swz4(row) (common.hpp); readers apply the same XOR.
     unsigned voff_t[MT], voff_h[MT];
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void pwattn_fwd_kernel(const FwdParams p) {
         const unsigned bt = mm / (unsigned)H;
         const unsigned b = bt / (unsigned)T;
         const unsigned hr = b * H + (mm - bt * H);
-        const unsigned slot = (unsigned)((lane & 3) ^ ((rl >> 2) & 3));
+        const unsigned slot = (unsigned)((lane & 3) ^ swz4(rl));
         voff_t[j] = m < M ? (bt * p.ldt + 4 * slot) * 4u : OOB;
         voff_h[j] = m < M ? (hr * p.ldh + 4 * slot) * 4u : OOB;
     }
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void pwattn_fwd_kernel(const FwdParams p) {
         voff_u[jt] = m < M ? (hr * p.ldu + 4 * q) * 4u : OOB;
         voff_v[jt] = m < M ? (bt * p.ldv + 4 * q) * 4u : OOB;
     }
-    const int rslot = 4 * (q ^ ((r16 >> 2) & 3));          // swizzled float offset of this lane's fragment slot
+    const int rslot = 4 * (q ^ swz4(r16));          // swizzled float offset of this lane's fragment slot
 
     float s_part[MT];
 #pragma unroll

@@ -10,7 +10,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnrm_hotpath.so")
+LIB_PATH = os.environ.get("NRM_HOTPATH_LIB") or os.path.join(_HERE, "libnrm_hotpath.so")   # override: diagnostic builds (scripts/_diag)
 ABI_VERSION = 1
 
 _c_fp = ctypes.c_void_p      # device pointers travel as integers
