@@ -18,12 +18,15 @@
 #ifndef NRM_PIPE_SGB
 #define NRM_PIPE_SGB 1
 #endif
-// timing diagnostics only (scripts/_diag/build_diag.sh): results are WRONG with either of them set
+// timing diagnostics only (scripts/_diag/build_diag.sh): results are WRONG with any of them set
 #ifndef NRM_DIAG_NOEPI
-#define NRM_DIAG_NOEPI 0      // pipelined dh kernel without its per-group epilogue
+#define NRM_DIAG_NOEPI 0      // contraction kernels without the per-group epilogue
+#endif
+#ifndef NRM_DIAG_NOATOM
+#define NRM_DIAG_NOATOM 0     // contraction kernels without the float atomics of the out-row flush
 #endif
 #ifndef NRM_DIAG_NOLOAD
-#define NRM_DIAG_NOLOAD 0     // pipelined dh kernel that never reloads its MFMA operands
+#define NRM_DIAG_NOLOAD 0     // contraction kernels that never reload MFMA operands (1: both, serial kernel also 2: X only, 3: Y only)
 #endif
 #include "common.hpp"
 #include "pwattn.hpp"
@@ -204,13 +207,17 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
         ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Y + (long)g1 * p.ys1), 0, ybytes, 0x00020000);
     };
     // operands of reduction step s (rows 4s..4s+3) of the open group, d tiles [J0, J0+NJ)
+    bool diag_first = true;
     auto load_step = [&](auto j0c, auto njc, float (&a)[KT], float (&b)[KS], int s) {
         constexpr int J0 = decltype(j0c)::value, NJ = decltype(njc)::value;
+        if (NRM_DIAG_NOLOAD == 1 && !diag_first) return;
+        if (!(NRM_DIAG_NOLOAD == 2 && !diag_first))
 #pragma unroll
         for (int it = 0; it < KT; ++it) {
             const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rx, vx + 64 * it, s * xstep, 0);
             a[it] = __uint_as_float(EXACT ? v : (v & mA[it]));
         }
+        if (!(NRM_DIAG_NOLOAD == 3 && !diag_first))
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) {
             const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(ry, vy + 64 * (J0 + jt), s * ystep, 0);
@@ -266,6 +273,15 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
         }
 
         // epilogue: lane holds E[k = k0+16it+4q+e][d = d0+16jt+r16]
+        if (NRM_DIAG_NOEPI && g + 1 < g_hi) {                        // timing diagnostic: one cheap use keeps E alive
+            float keep = 0.f;
+#pragma unroll
+            for (int it = 0; it < KT; ++it)
+#pragma unroll
+                for (int jt = 0; jt < NJ; ++jt) keep += E[it][jt][0];
+            if (keep == 123.456f) bounce[r16] = keep;
+            return;
+        }
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) {
             const int dl = 16 * (J0 + jt) + r16;
@@ -288,6 +304,7 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
         load_step(IC<0>{}, IC<KS>{}, a0, b0, 0);
         if (nsteps > 1) load_step(IC<0>{}, IC<KS>{}, a1, b1, 1);
     }
+    diag_first = false;
     for (int g = g_lo; g < g_hi; ++g) {
         if constexpr (KS == DT) {
             sub_pass(IC<0>{}, IC<DT>{}, IC<0>{}, IC<DT>{}, g, g + 1, true);
@@ -297,13 +314,14 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
         }
         // k-partial of out[g, d0 .. d0+DT*16): one dword per lane, contiguous segments.
         // bounce[] is wave-private: LDS ops of one wave complete in order, the fences only pin hipcc.
+        if (NRM_DIAG_NOEPI && g + 1 < g_hi) continue;
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         __builtin_amdgcn_wave_barrier();
         float* orow = p.out + (long)g * p.ldo + d0;
 #pragma unroll
         for (int c = 0; c < DT * 16; c += 64) {
             const int dl = c + lane;
-            if (dl < DT * 16 && (EXACT || d0 + dl < D)) atomicAdd(orow + dl, bounce[dl]);
+            if (!NRM_DIAG_NOATOM && dl < DT * 16 && (EXACT || d0 + dl < D)) atomicAdd(orow + dl, bounce[dl]);
         }
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         __builtin_amdgcn_wave_barrier();
@@ -395,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void bwd_e_pipe_kernel(const BwdEParams p) 
     };
     bool diag_first = true;
     auto load_step = [&](__amdgpu_buffer_rsrc_t dx, __amdgpu_buffer_rsrc_t dy, float (&a)[KT], float (&b)[DT], int s) {
-        if (NRM_DIAG_NOLOAD && !(diag_first && s < 2)) return;
+        if (NRM_DIAG_NOLOAD == 1 && !(diag_first && s < 2)) return;
 #pragma unroll
         for (int it = 0; it < KT; ++it) {
             const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(dx, vx + 64 * it, s * xstep, 0);
@@ -433,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void bwd_e_pipe_kernel(const BwdEParams p) 
 #pragma unroll
         for (int c = 0; c < DT * 16; c += 64) {
             const int dl = c + lane;
-            if (dl < DT * 16 && (EXACT || d0 + dl < D)) atomicAdd(orow + dl, bounce[dl]);
+            if (!NRM_DIAG_NOATOM && dl < DT * 16 && (EXACT || d0 + dl < D)) atomicAdd(orow + dl, bounce[dl]);
         }
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         __builtin_amdgcn_wave_barrier();
