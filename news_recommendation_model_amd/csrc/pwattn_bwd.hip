@@ -26,7 +26,7 @@
 #define NRM_DIAG_NOATOM 0     // contraction kernels without the float atomics of the out-row flush
 #endif
 #ifndef NRM_DIAG_NOLOAD
-#define NRM_DIAG_NOLOAD 0     // contraction kernels that never reload MFMA operands (1: both, serial kernel also 2: X only, 3: Y only)
+#define NRM_DIAG_NOLOAD 0     // contraction kernels that never reload MFMA operands (1: both; serial kernel also 2: X only, 3: Y only, 4: reload step 0 of the group every time)
 #endif
 #include "common.hpp"
 #include "pwattn.hpp"
@@ -211,6 +211,7 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
     auto load_step = [&](auto j0c, auto njc, float (&a)[KT], float (&b)[KS], int s) {
         constexpr int J0 = decltype(j0c)::value, NJ = decltype(njc)::value;
         if (NRM_DIAG_NOLOAD == 1 && !diag_first) return;
+        if (NRM_DIAG_NOLOAD == 4) s = 0;                              // same instruction stream, always the same (L1-resident) rows
         if (!(NRM_DIAG_NOLOAD == 2 && !diag_first))
 #pragma unroll
         for (int it = 0; it < KT; ++it) {
