@@ -135,6 +135,10 @@ class UserInvariantInterestModel(nn.Module):
 
     def forward(self, x_history, x_target):
         ops._require_gpu(x_history, x_target)
+        if x_history.shape[0] * x_history.shape[1] == 0 or x_target.shape[1] == 0:
+            # same error as the reference, whose feature_embedding reshapes with a -1 dimension (:59); the ops below
+            # would accept empty inputs (ops._degenerate), the drop-in keeps the reference's behaviour
+            raise RuntimeError("cannot reshape tensor of 0 elements (empty batch / history / candidate list)")
         lab_h, ti_h = self._embed(x_history, True)         # [B,H,D_l+2], [B,H,P]
         lab_t, ti_t = self._embed(x_target, False)         # [B,T,D_l],   [B,T,P]
         lab_h = ops.linear(lab_h, self.w1.weight, self.w1.bias)

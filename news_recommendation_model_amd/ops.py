@@ -23,6 +23,19 @@ def _f32c(x):
     return x.to(torch.float32).contiguous()
 
 
+def _degenerate(shape, *deps):
+    """fp32 zeros of `shape` for an input with no rows (empty batch, empty history, no candidates): what the
+    reference's ATen ops return there.  The result stays connected, with exactly-zero gradients, to every input
+    that requires grad, as the reference's graph would be."""
+    tensors = [d for d in deps if isinstance(d, torch.Tensor)]
+    _require_gpu(*tensors)
+    out = torch.zeros(shape, dtype=torch.float32, device=tensors[0].device)
+    for d in tensors:
+        if d.requires_grad:
+            out = out + d.reshape(-1)[:0].sum().to(torch.float32)     # sum of nothing: 0, but a graph edge
+    return out
+
+
 class _PointwiseAttentionScores(torch.autograd.Function):
     """s[b,t,h] = fc2(GELU(fc1(cat[h, t, t-h, t*h]))) with fc1 = [W_h|W_t|W_d|W_p] re-associated as
     z = h(W_h-W_d)^T + b1 + t(W_t+W_d)^T + sum_d W_p[:,d] t_d h_d  (SURVEY.md §8 a7)."""
@@ -102,6 +115,9 @@ def pointwise_attention_scores(target, history, fc1_weight, fc1_bias, fc2_weight
     differentiable ops: padded features contribute exactly 0 to every term (their fc1 rows/columns and fc2 weights
     are 0, gelu(0) = 0), and autograd slices the gradients back."""
     D = target.shape[-1]
+    if target.shape[0] * target.shape[1] * history.shape[1] == 0:
+        return _degenerate((target.shape[0], target.shape[1], history.shape[1]), target, history, fc1_weight, fc1_bias,
+                           fc2_weight, fc2_bias)
     if D % 4 == 0:
         return _PointwiseAttentionScores.apply(target, history, fc1_weight, fc1_bias, fc2_weight, fc2_bias)
     _require_gpu(target, history, fc1_weight)
@@ -198,6 +214,8 @@ class _Linear(torch.autograd.Function):
 def linear(x, weight, bias=None, gelu=False):
     """nn.Linear (optionally followed by exact GELU) on the last dimension of x."""
     lead = x.shape[:-1]
+    if x.numel() == 0 and x.shape[-1] == weight.shape[1]:
+        return _degenerate((*lead, weight.shape[0]), x, weight, bias)
     y = _Linear.apply(x.reshape(-1, x.shape[-1]), weight, bias, bool(gelu))
     return y.reshape(*lead, weight.shape[0])
 
@@ -258,6 +276,8 @@ def batch_norm(x, bn):
     if (x.dim() != 2 or x.shape[1] % 4 or not bn.affine or not bn.track_running_stats or bn.momentum is None):
         return bn(x)
     training = bn.training
+    if x.shape[0] <= (1 if training else 0):
+        return bn(x)          # 0/1 rows in training: nn.BatchNorm1d raises its ValueError; 0 rows in eval: empty result
     if training:
         bn.num_batches_tracked.add_(1)
     return _BatchNorm.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, float(bn.momentum),
@@ -297,6 +317,8 @@ class _WeightedPool(torch.autograd.Function):
 
 def weighted_pool(scores, history):
     D = history.shape[-1]
+    if scores.numel() == 0:                                  # empty batch / no candidates / empty history: sum of nothing
+        return _degenerate((scores.shape[0], scores.shape[1], D), scores, history)
     if D % 4 == 0:
         return _WeightedPool.apply(scores, history)
     _require_gpu(scores, history)
@@ -331,6 +353,8 @@ class _SoftmaxBceLoss(torch.autograd.Function):
 
 
 def softmax_bce_loss(out, delta, label, user_id, alpha):
+    if out.numel() == 0:                                     # nn.BCELoss: mean over no elements
+        return _degenerate((), out, delta) + float("nan")
     return _SoftmaxBceLoss.apply(out, delta, label, user_id, alpha)
 
 
@@ -409,6 +433,10 @@ class _Frontend(torch.autograd.Function):
 def frontend(x, behaviour, n_sub, P, cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab):
     """x [B, N, cols] -> (label rows [B, N, width], text/image rows [B, N, P])."""
     B, N = x.shape[0], x.shape[1]
+    if B * N == 0:
+        tabs = (cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab)
+        width = cat_tab.shape[1] + sen_w.shape[0] + type_tab.shape[1] + year_tab.shape[1] + (2 if behaviour else 0)
+        return _degenerate((B, N, width), x, *tabs), _degenerate((B, N, int(P)), x)
     lab, ti = _Frontend.apply(x.reshape(B * N, x.shape[2]), bool(behaviour), int(n_sub), int(P), cat_tab, sen_w, sen_b,
                               type_tab, year_tab, month_tab, day_tab, hour_tab)
     return lab.reshape(B, N, -1) if lab.is_contiguous() else lab.unflatten(0, (B, N)), ti.unflatten(0, (B, N))

@@ -210,7 +210,53 @@ def attention_2d_case(outdir):
     return {"scores": float((s.detach() - s_o).abs().max())}
 
 
+def degenerate_case(outdir):
+    """What the REFERENCE does with no rows: empty history (a real forward), empty batch (eval: empty result,
+    train: BatchNorm raises), a single training row (BatchNorm raises), BCELoss over nothing (nan)."""
+    dims = Dims.for_emb(16, 40)
+    UserModel = build_reference(dims)
+    sd = synth.make_state_dict(dims, seed=3, user_num=5)
+    model = UserModel(5)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+    batch = synth.make_batch(dims, 3, 2, 4, seed=11, user_num=5)
+    xh = torch.from_numpy(batch["x_history"]).float()
+    xt = torch.from_numpy(batch["x_target"]).float()
+    xg = torch.from_numpy(batch["x_global"]).float()
+    beh = {}
+
+    def outcome(fn):
+        try:
+            out = fn()
+            return "shape:" + "x".join(str(int(d)) for d in out.shape)
+        except Exception as e:                                     # noqa: BLE001 -- the exception type IS the datum
+            return "raises:" + type(e).__name__
+    for mode in ("train", "eval"):
+        model.train(mode == "train")
+        with torch.no_grad():
+            beh["empty_history_" + mode] = outcome(lambda: model(xh[:, :0], xt, xg))
+            beh["empty_batch_" + mode] = outcome(lambda: model(xh[:0], xt[:0], xg[:0]))
+            beh["no_candidates_" + mode] = outcome(lambda: model(xh, xt[:, :0], xg[:, :0]))
+            beh["single_row_" + mode] = outcome(lambda: model(xh[:1], xt[:1, :1], xg[:1, :1]))
+    att = model.invariant_interest_model.text_img_attention
+    D = dims.pca_vector
+    for name, (B, T, H) in {"B0": (0, 3, 4), "T0": (2, 0, 4), "H0": (2, 3, 0)}.items():
+        beh["attention_" + name] = outcome(lambda: att(torch.zeros(B, T, D), torch.zeros(B, H, D)))
+    beh["empty_batch_loss"] = outcome(lambda: model.loss(torch.zeros(0, dtype=torch.long), torch.zeros(0, 4), torch.zeros(0, 4)))
+    loss = model.loss(torch.zeros(0, dtype=torch.long), torch.zeros(0, 4), torch.zeros(0, 4))
+    beh["empty_batch_loss_is_nan"] = bool(torch.isnan(loss))
+    return beh
+
+
 def main():
+    if "--only-degenerate" in sys.argv:                             # add / refresh that one entry, leave the rest alone
+        outdir = os.path.join(ROOT, "tests", "golden")
+        with open(os.path.join(outdir, "MANIFEST.json")) as f:
+            manifest = json.load(f)
+        manifest["degenerate"] = degenerate_case(outdir)
+        print("degenerate", manifest["degenerate"])
+        with open(os.path.join(outdir, "MANIFEST.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
     torch.manual_seed(0)
     torch.set_num_threads(8)
     outdir = os.path.join(ROOT, "tests", "golden")
@@ -223,6 +269,8 @@ def main():
         print(name, diffs, flush=True)
     manifest["cases"]["attention_2d"] = {"case": {"B": 3, "H": 11, "D": 64}, "oracle_vs_reference": attention_2d_case(outdir)}
     print("attention_2d", manifest["cases"]["attention_2d"]["oracle_vs_reference"])
+    manifest["degenerate"] = degenerate_case(outdir)
+    print("degenerate", manifest["degenerate"])
     with open(os.path.join(outdir, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
 

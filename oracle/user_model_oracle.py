@@ -79,6 +79,11 @@ def invariant_interest(p, x_history, x_target, n_sub=5, n_sent=3, return_aux=Fal
     inv = "invariant_interest_model."
     P = p[inv + "text_img_attention.mlp.fc2.weight"].shape[1]
     widths = [4, P, 1, n_sub, n_sent, 1, 1, 1]
+    if x_history.shape[0] * x_history.shape[1] == 0 or x_target.shape[1] == 0:
+        # :59 reshapes the embedded ids with a -1 dimension, which ATen refuses for 0 elements: the reference model
+        # raises RuntimeError for an empty batch, an empty history and an empty candidate list (train and eval;
+        # tests/golden/MANIFEST.json "degenerate").  The attention module alone accepts them (empty scores).
+        raise RuntimeError("cannot reshape tensor of 0 elements (empty batch / history / candidate list)")
     time_h, ti_h, cat_h, sub_h, sen_h, typ_h, read_h, scroll_h = _split_cols(x_history.float(), widths)
     time_t, ti_t, cat_t, sub_t, sen_t, typ_t = _split_cols(x_target.float(), widths[:6])
 
@@ -114,6 +119,8 @@ def user_model_forward(p, x_history, x_target, x_global, training=True, bn_state
     B, T, N = e.shape
     e2 = e.reshape(B * T, N)
     if training:
+        if e2.shape[0] <= 1:      # nn.BatchNorm1d in training mode (user_model.py:32)
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {list(e2.shape)}")
         mean = e2.mean(dim=0)
         var_b = e2.var(dim=0, unbiased=False)
         if bn_state is not None:

@@ -64,3 +64,39 @@ def test_row_auc_ties_and_errors():
     assert orc.row_auc([1, 0, 0, 0], [0.2, 0.2, 0.1, 0.9]) == pytest.approx((1 + 0.5) / 3)
     with pytest.raises(ValueError):
         orc.row_auc([0, 0], [0.1, 0.2])
+
+
+def test_oracle_degenerate_inputs_behave_like_the_reference():
+    """MANIFEST "degenerate" = what the reference model does with no rows (recorded by oracle/make_golden.py from the
+    reference itself): the oracle must raise / return the same."""
+    import json
+    import os
+    from golden_util import GOLDEN
+    from news_recommendation_model_amd import config, synth
+    with open(os.path.join(GOLDEN, "MANIFEST.json")) as f:
+        want = json.load(f)["degenerate"]
+    dims = config.Dims.for_emb(16, 40)
+    p = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_state_dict(dims, seed=3, user_num=5).items()}
+    batch = synth.make_batch(dims, 3, 2, 4, seed=11, user_num=5)
+    xh, xt, xg = (torch.from_numpy(batch[k]).float() for k in ("x_history", "x_target", "x_global"))
+
+    def probe(fn):
+        try:
+            out = fn()
+            return "shape:" + "x".join(str(int(d)) for d in out.shape)
+        except Exception as e:                                     # noqa: BLE001
+            return "raises:" + type(e).__name__
+    for mode in ("train", "eval"):
+        tr = mode == "train"
+        got = {"empty_history_" + mode: probe(lambda: orc.user_model_forward(p, xh[:, :0], xt, xg, training=tr)),
+               "empty_batch_" + mode: probe(lambda: orc.user_model_forward(p, xh[:0], xt[:0], xg[:0], training=tr)),
+               "no_candidates_" + mode: probe(lambda: orc.user_model_forward(p, xh, xt[:, :0], xg[:, :0], training=tr)),
+               "single_row_" + mode: probe(lambda: orc.user_model_forward(p, xh[:1], xt[:1, :1], xg[:1, :1], training=tr))}
+        for k, v in got.items():
+            assert v == want[k], (k, v, want[k])
+    pre = "invariant_interest_model.text_img_attention"
+    D = dims.pca_vector
+    for name, (B, T, H) in {"B0": (0, 3, 4), "T0": (2, 0, 4), "H0": (2, 3, 0)}.items():
+        assert probe(lambda: orc.pointwise_attention_scores(p, pre, torch.zeros(B, T, D), torch.zeros(B, H, D))) == want["attention_" + name]
+    loss = orc.user_model_loss(p, torch.zeros(0, dtype=torch.long), torch.zeros(0, 4), torch.zeros(0, 4))
+    assert bool(torch.isnan(loss)) == want["empty_batch_loss_is_nan"]
