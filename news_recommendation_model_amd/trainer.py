@@ -198,3 +198,71 @@ def batch_to_device(batch_np, device="cuda", dtype=None):
             t = t.to(dtype)
         out[k] = t.to(device)
     return out
+
+
+class BatchPrefetcher:
+    """Host -> HBM staging of DataLoader batches on a side stream, one batch ahead of the step.
+
+    The reference moves every field with ``.to(device)`` inside the step (train.py:66-68), float64 as the DataLoader
+    yields it; at C3 that is 272 MB per step.  Here the next batch is copied from pinned host memory into one of two
+    preallocated device buffer sets on a copy stream while the current step runs; the compute stream waits on the
+    copy's event, and a buffer is only overwritten after the step that read it has been enqueued (its event)."""
+
+    def __init__(self, batches, device="cuda", pin=True):
+        self.device = torch.device(device)
+        self.batches = iter(batches)
+        self.pin = pin
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.bufs = [None, None]
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]      # copy finished
+        self.free = [None, None]                                    # step that consumed the buffer enqueued
+        self.slot = 0
+        self._pending = None
+        self._stage()
+
+    def _host(self, batch):
+        out = {}
+        for k, v in batch.items():
+            if k == "user_num":
+                continue
+            t = torch.as_tensor(v)
+            out[k] = t.pin_memory() if self.pin and not t.is_pinned() else t
+        return out
+
+    def _stage(self):
+        try:
+            host = self._host(next(self.batches))
+        except StopIteration:
+            self._pending = None
+            return
+        i = self.slot
+        if self.bufs[i] is None or any(self.bufs[i][k].shape != v.shape or self.bufs[i][k].dtype != v.dtype
+                                       for k, v in host.items()):
+            self.bufs[i] = {k: torch.empty(v.shape, dtype=v.dtype, device=self.device) for k, v in host.items()}
+            self.free[i] = None
+        with torch.cuda.stream(self.copy_stream):
+            if self.free[i] is not None:
+                self.copy_stream.wait_event(self.free[i])
+            for k, v in host.items():
+                self.bufs[i][k].copy_(v, non_blocking=True)
+            self.ready[i].record(self.copy_stream)
+        self._pending = (i, host)                                   # keep the pinned tensors alive until consumed
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._pending is None:
+            raise StopIteration
+        i, _host = self._pending
+        torch.cuda.current_stream(self.device).wait_event(self.ready[i])
+        batch = self.bufs[i]
+        self.slot = 1 - i
+        self._stage()                                               # next copy overlaps the step about to be enqueued
+        return batch, i
+
+    def release(self, slot):
+        """Call after the step that read buffer set ``slot`` has been enqueued on the current stream."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.free[slot] = ev
