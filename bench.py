@@ -292,6 +292,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(dims, wl, args.cpu_seconds, args.cpu_batch)
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()                 # rank 0 is still printing / probing parity: leave together
         dist.destroy_process_group()
 
 
