@@ -122,15 +122,20 @@ hipError_t bwd_dz_launch(float* z, const float* ds, const float* w2, float* dw2,
 // atomics shaped as contiguous 256-B segments (nkw adds per output element; `out` is initialised by the
 // caller) and stores its dW_p^T partial as one slab per split.
 //
-// KS < DT splits the wave's d-range into two sub-passes per group ([0,KS) then [KS,DT)) so that only KT*KS
-// tiles of E are live beside the KT*DT tiles of dW_p (register budget for 2 waves/SIMD).
+// KS is kept in the signature for the launch table only (KS == DT: one pass over the tile per group).
 // EXACT: D is a multiple of both tile widths -> no column masks / clamped offsets (fewer VGPRs and VALU).
 template <int N> struct IC { static constexpr int value = N; };
+
+// Column layout of the wide-load contraction kernel: local column c of an 80-wide (or 64-wide) wave tile lives in MFMA
+// tile c&3 at lane-row c>>2 for c < 64 and in tile 4 at lane-row c-64 above; tile_pos is where that column sits in the
+// tile-major order (16*tile + row) the LDS W_p^T image and the accumulators are indexed by.
+__device__ __forceinline__ int tile_col(int tile, int row) { return tile < 4 ? 4 * row + tile : 64 + row; }
+__device__ __forceinline__ int tile_pos(int c) { return c < 64 ? 16 * (c & 3) + (c >> 2) : c; }
 
 template <int KT, int DT, int KS, bool WITH_DW, bool EXACT>
 __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-descriptor builtins: device pass only (keeps the host stub)
-    static_assert(KS <= DT && DT - KS <= KS, "first sub-pass must be the larger one");
+    static_assert(KS == DT, "one pass over the whole d range per group (the 3+2 sub-pass split is gone)");
     constexpr int LDK = KT * 16 + 8;      // padded row of the W_p^T tile: +8 is conflict-free under gfx950 b128 lane groups (+4 is 2-way)
     __shared__ __attribute__((aligned(16))) float smem[DT * 16 * LDK + 4 * DT * 16];
     float* wpt = smem;                                                  // [DT*16 d][LDK]  = W_p[k0+k][d0+d]
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
         f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
         if (k < D && d < D) w = *reinterpret_cast<const f32x4*>(p.wp + (long)k * p.ldwp + d);     // D % 4 == 0
 #pragma unroll
-        for (int e = 0; e < 4; ++e) wpt[(4 * d4 + e) * LDK + kl] = w[e];
+        for (int e = 0; e < 4; ++e) wpt[tile_pos(4 * d4 + e) * LDK + tile_pos(kl)] = w[e];
     }
     __syncthreads();
 
@@ -174,21 +179,19 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
 
     // Operands stream from global memory straight into MFMA operand registers through buffer descriptors
     // rebuilt per group (uniform base = the group's first row, extent = R rows): the per-lane part of the
-    // address is ONE loop-invariant 32-bit offset (row q of the step, column of the lane), the step advances
+    // address is a loop-invariant 32-bit offset (row q of the step, columns of the lane), the step advances
     // the scalar offset, and rows >= R read as 0 by the hardware bounds check -- no masks, no address VALU.
-    // General (non-EXACT) shapes also mask the columns >= D of the last tile.
-    const unsigned vx = (unsigned)((long)q * p.xrs + k0 + r16) * 4u;
-    const unsigned vy = (unsigned)((long)q * p.yrs + d0 + r16) * 4u;
+    // Column layout (tile_col): ONE 16-byte load per lane feeds tiles 0..3 and one dword load tile 4, i.e. 4
+    // vector-memory instructions per reduction step, each a set of whole 256-B / 64-B row segments.
+    // Columns >= D (general shapes) get the out-of-range offset and read as 0.
+    constexpr unsigned OOB = 0x80000000u;
+    const unsigned vx4 = (EXACT || k0 + 4 * r16 < D) ? (unsigned)((long)q * p.xrs + k0 + 4 * r16) * 4u : OOB;
+    const unsigned vx1 = (EXACT || k0 + 64 + r16 < D) ? (unsigned)((long)q * p.xrs + k0 + 64 + r16) * 4u : OOB;
+    const unsigned vy4 = (EXACT || d0 + 4 * r16 < D) ? (unsigned)((long)q * p.yrs + d0 + 4 * r16) * 4u : OOB;
+    const unsigned vy1 = (EXACT || d0 + 64 + r16 < D) ? (unsigned)((long)q * p.yrs + d0 + 64 + r16) * 4u : OOB;
     const unsigned xbytes = (unsigned)(((long)(R - 1) * p.xrs + D) * 4);
     const unsigned ybytes = (unsigned)(((long)(R - 1) * p.yrs + D) * 4);
     const int xstep = (int)(p.xrs * 16), ystep = (int)(p.yrs * 16);     // 4 rows, bytes
-    unsigned mA[EXACT ? 1 : KT], mB[EXACT ? 1 : DT];
-    if (!EXACT) {
-#pragma unroll
-        for (int it = 0; it < KT; ++it) mA[it] = k0 + 16 * it + r16 < D ? 0xffffffffu : 0u;
-#pragma unroll
-        for (int jt = 0; jt < DT; ++jt) mB[jt] = d0 + 16 * jt + r16 < D ? 0xffffffffu : 0u;
-    }
 
     f32x4 dW[KT][DT];
     if (WITH_DW) {
@@ -199,120 +202,121 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
     }
 
     // two operand register sets (ping-pong, no copies)
-    float a0[KT], b0[KS], a1[KT], b1[KS];
+    float a0[KT], b0[DT], a1[KT], b1[DT];
     __amdgpu_buffer_rsrc_t rx, ry;
     auto open_group = [&](int gg) {
         const int g1 = gg / p.G2, g2 = gg - g1 * p.G2;
         rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X + (long)g1 * p.xs1 + (long)g2 * p.xs2), 0, xbytes, 0x00020000);
         ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Y + (long)g1 * p.ys1), 0, ybytes, 0x00020000);
     };
-    // operands of reduction step s (rows 4s..4s+3) of the open group, d tiles [J0, J0+NJ)
+    // operands of reduction step s (rows 4s..4s+3) of the open group
     bool diag_first = true;
-    auto load_step = [&](auto j0c, auto njc, float (&a)[KT], float (&b)[KS], int s) {
-        constexpr int J0 = decltype(j0c)::value, NJ = decltype(njc)::value;
+    auto load_step = [&](float (&a)[KT], float (&b)[DT], int s) {
         if (NRM_DIAG_NOLOAD == 1 && !diag_first) return;
         if (NRM_DIAG_NOLOAD == 4) s = 0;                              // same instruction stream, always the same (L1-resident) rows
-        if (!(NRM_DIAG_NOLOAD == 2 && !diag_first))
+        if (!(NRM_DIAG_NOLOAD == 2 && !diag_first)) {
+            const u32x4 va = __builtin_amdgcn_raw_buffer_load_b128(rx, vx4, s * xstep, 0);
 #pragma unroll
-        for (int it = 0; it < KT; ++it) {
-            const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rx, vx + 64 * it, s * xstep, 0);
-            a[it] = __uint_as_float(EXACT ? v : (v & mA[it]));
+            for (int e = 0; e < 4; ++e) a[e] = __uint_as_float(va[e]);
         }
-        if (!(NRM_DIAG_NOLOAD == 3 && !diag_first))
+        if (!(NRM_DIAG_NOLOAD == 3 && !diag_first)) {
+            const u32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(ry, vy4, s * ystep, 0);
 #pragma unroll
-        for (int jt = 0; jt < NJ; ++jt) {
-            const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(ry, vy + 64 * (J0 + jt), s * ystep, 0);
-            b[jt] = __uint_as_float(EXACT ? v : (v & mB[J0 + jt]));
+            for (int e = 0; e < 4; ++e) b[e] = __uint_as_float(vb[e]);
         }
+        if (KT > 4 && !(NRM_DIAG_NOLOAD == 2 && !diag_first))
+            a[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx1, s * xstep, 0));
+        if (DT > 4 && !(NRM_DIAG_NOLOAD == 3 && !diag_first))
+            b[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, vy1, s * ystep, 0));
     };
 
-    // one sub-pass of group g over d tiles [J0, J0+NJ).  On entry sets 0 and 1 hold steps 0 and 1.  After its
-    // last MFMA batch it prefetches steps 0 and 1 of the following sub-pass (tiles [NJ0, NJ0+NNJ) of group gn):
-    // their latency hides under the epilogue, and -- vmcnt retires in issue order -- the first load issued AFTER
-    // this group's float atomics is then only needed two MFMA batches later.
-    auto sub_pass = [&](auto j0c, auto njc, auto nj0c, auto nnjc, int g, int gn, bool first_of_group) {
-        constexpr int J0 = decltype(j0c)::value, NJ = decltype(njc)::value;
-        // scale rows of this group for the dW_p update: loaded here, consumed in the epilogue
-        float sr[NJ];
+    // One group: on entry sets 0 and 1 hold steps 0 and 1.  After its last MFMA batch it prefetches steps 0 and 1 of
+    // group gn: their latency hides under the epilogue, and -- vmcnt retires in issue order -- the first load issued
+    // AFTER this group's float atomics is then only needed two MFMA batches later.
+    auto group_pass = [&](int g, int gn) {
+        // scale row of this group for the dW_p update: loaded here, consumed in the epilogue
+        float sr[DT];
+        if (WITH_DW) {
+            const float* srow = p.srow + (long)g * p.lds_;
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(srow + ((EXACT || d0 + 4 * r16 < D) ? d0 + 4 * r16 : 0));
 #pragma unroll
-        for (int jt = 0; jt < NJ; ++jt) {
-            sr[jt] = 0.f;
-            if (WITH_DW) {
-                const int d = d0 + 16 * (J0 + jt) + r16;
-                sr[jt] = p.srow[(long)g * p.lds_ + (EXACT || d < D ? d : 0)];
-            }
+            for (int e = 0; e < 4; ++e) sr[e] = s4[e];
+            if (DT > 4) sr[4] = srow[(EXACT || d0 + 64 + r16 < D) ? d0 + 64 + r16 : 0];
         }
-        f32x4 E[KT][NJ];
-        auto mfma_batch = [&](const float (&a)[KT], const float (&b)[KS]) {
+        f32x4 E[KT][DT];
+        auto mfma_batch = [&](const float (&a)[KT], const float (&b)[DT]) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it)                              // fed by the two 16-byte loads
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) E[it][jt] = mfma16(a[it], b[jt], E[it][jt]);
 #pragma unroll
             for (int it = 0; it < KT; ++it)
 #pragma unroll
-                for (int jt = 0; jt < NJ; ++jt) E[it][jt] = mfma16(a[it], b[jt], E[it][jt]);
+                for (int jt = (it < 4 ? 4 : 0); jt < DT; ++jt) E[it][jt] = mfma16(a[it], b[jt], E[it][jt]);
         };
         // step 0 accumulates onto an inline-constant 0 (no accumulator clearing)
 #pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) E[it][jt] = mfma16(a0[it], b0[jt], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
         for (int it = 0; it < KT; ++it)
 #pragma unroll
-            for (int jt = 0; jt < NJ; ++jt) E[it][jt] = mfma16(a0[it], b0[jt], f32x4{0.f, 0.f, 0.f, 0.f});
-        if (2 < nsteps) load_step(j0c, njc, a0, b0, 2);
+            for (int jt = (it < 4 ? 4 : 0); jt < DT; ++jt) E[it][jt] = mfma16(a0[it], b0[jt], f32x4{0.f, 0.f, 0.f, 0.f});
+        if (2 < nsteps) load_step(a0, b0, 2);
         if (1 < nsteps) {
             mfma_batch(a1, b1);
-            if (3 < nsteps) load_step(j0c, njc, a1, b1, 3);
+            if (3 < nsteps) load_step(a1, b1, 3);
         }
         for (int s = 2; s < nsteps; s += 2) {
             mfma_batch(a0, b0);
-            if (s + 2 < nsteps) load_step(j0c, njc, a0, b0, s + 2);
+            if (s + 2 < nsteps) load_step(a0, b0, s + 2);
             if (s + 1 < nsteps) {
                 mfma_batch(a1, b1);
-                if (s + 3 < nsteps) load_step(j0c, njc, a1, b1, s + 3);
+                if (s + 3 < nsteps) load_step(a1, b1, s + 3);
             }
         }
         if (gn < g_hi) {
-            if (gn != g) open_group(gn);
-            load_step(nj0c, nnjc, a0, b0, 0);
-            if (nsteps > 1) load_step(nj0c, nnjc, a1, b1, 1);
+            open_group(gn);
+            load_step(a0, b0, 0);
+            if (nsteps > 1) load_step(a1, b1, 1);
         }
 
-        // epilogue: lane holds E[k = k0+16it+4q+e][d = d0+16jt+r16]
+        // epilogue: lane holds E[k = k0 + tile_col(it, 4q+e)][d = d0 + tile_col(jt, r16)]; the LDS image of W_p^T is
+        // in tile-major order (tile_pos), so its rows/columns are addressed by 16*tile + lane-row as the accumulators are
         if (NRM_DIAG_NOEPI && g + 1 < g_hi) {                        // timing diagnostic: one cheap use keeps E alive
             float keep = 0.f;
 #pragma unroll
             for (int it = 0; it < KT; ++it)
 #pragma unroll
-                for (int jt = 0; jt < NJ; ++jt) keep += E[it][jt][0];
+                for (int jt = 0; jt < DT; ++jt) keep += E[it][jt][0];
             if (keep == 123.456f) bounce[r16] = keep;
             return;
         }
 #pragma unroll
-        for (int jt = 0; jt < NJ; ++jt) {
-            const int dl = 16 * (J0 + jt) + r16;
+        for (int jt = 0; jt < DT; ++jt) {
+            const int dl = 16 * jt + r16;
             float acc = 0.f;
 #pragma unroll
             for (int it = 0; it < KT; ++it) {
                 const f32x4 w4 = *reinterpret_cast<const f32x4*>(&wpt[dl * LDK + 16 * it + 4 * q]);
                 const f32x4 e4 = E[it][jt];
                 acc = fmaf(w4[0], e4[0], fmaf(w4[1], e4[1], fmaf(w4[2], e4[2], fmaf(w4[3], e4[3], acc))));
-                if (WITH_DW) dW[it][J0 + jt] += e4 * sr[jt];
+                if (WITH_DW) dW[it][jt] += e4 * sr[jt];
             }
             acc = sum_rows4(acc);
-            if (q == 0) bounce[dl] = acc;
+            if (q == 0) bounce[tile_col(jt, r16)] = acc;
         }
-        (void)first_of_group;
     };
 
     if (g_lo < g_hi) {
         open_group(g_lo);
-        load_step(IC<0>{}, IC<KS>{}, a0, b0, 0);
-        if (nsteps > 1) load_step(IC<0>{}, IC<KS>{}, a1, b1, 1);
+        load_step(a0, b0, 0);
+        if (nsteps > 1) load_step(a1, b1, 1);
     }
     diag_first = false;
     for (int g = g_lo; g < g_hi; ++g) {
-        if constexpr (KS == DT) {
-            sub_pass(IC<0>{}, IC<DT>{}, IC<0>{}, IC<DT>{}, g, g + 1, true);
-        } else {
-            sub_pass(IC<0>{}, IC<KS>{}, IC<KS>{}, IC<DT - KS>{}, g, g, true);
-            sub_pass(IC<KS>{}, IC<DT - KS>{}, IC<0>{}, IC<KS>{}, g, g + 1, false);
-        }
+        group_pass(g, g + 1);
         // k-partial of out[g, d0 .. d0+DT*16): one dword per lane, contiguous segments.
         // bounce[] is wave-private: LDS ops of one wave complete in order, the fences only pin hipcc.
         if (NRM_DIAG_NOEPI && g + 1 < g_hi) continue;
@@ -329,15 +333,22 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
     }
 
     if (WITH_DW) {      // slab layout is TRANSPOSED: ws[split][d][k]
+        // lane holds dW[it][jt][e] = dW_p[k0 + tile_col(it, 4q+e)][d0 + tile_col(jt, r16)]: for one d, tiles 0..3 cover
+        // the 16 consecutive k  k0 + 16q + 4e + it  (a float4 per e, gathered across the four accumulators) and tile 4
+        // the 4 consecutive k  k0 + 64 + 4q + e.
         float* wsp = p.ws + (long)split * D * D;
 #pragma unroll
         for (int jt = 0; jt < DT; ++jt) {
-            const int d = d0 + 16 * jt + r16;
+            const int d = d0 + tile_col(jt, r16);
+            if (!(EXACT || d < D)) continue;
+            float* row = wsp + (long)d * D + k0;
 #pragma unroll
-            for (int it = 0; it < KT; ++it) {
-                const int k = k0 + 16 * it + 4 * q;
-                if (EXACT || (k < D && d < D)) *reinterpret_cast<f32x4*>(wsp + (long)d * D + k) = dW[it][jt];
+            for (int e = 0; e < 4; ++e) {
+                const int kk = 16 * q + 4 * e;
+                if (EXACT || k0 + kk < D)
+                    *reinterpret_cast<f32x4*>(row + kk) = f32x4{dW[0][jt][e], dW[1][jt][e], dW[2][jt][e], dW[3][jt][e]};
             }
+            if (KT > 4 && (EXACT || k0 + 64 + 4 * q < D)) *reinterpret_cast<f32x4*>(row + 64 + 4 * q) = dW[KT - 1][jt];
         }
     }
 #endif
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void bwd_e_pipe_kernel(const BwdEParams p) 
         f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
         if (k < D && d < D) w = *reinterpret_cast<const f32x4*>(p.wp + (long)k * p.ldwp + d);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) wpt[(4 * d4 + e) * LDK + kl] = w[e];
+        for (int e = 0; e < 4; ++e) wpt[tile_pos(4 * d4 + e) * LDK + tile_pos(kl)] = w[e];
     }
     __syncthreads();
 
@@ -392,18 +403,18 @@ __global__ __launch_bounds__(256, 2) void bwd_e_pipe_kernel(const BwdEParams p) 
     if (g_lo >= g_hi) return;
     const int nsteps = (R + 3) >> 2;
 
-    const unsigned vx = (unsigned)((long)q * p.xrs + k0 + r16) * 4u;
-    const unsigned vy = (unsigned)((long)q * p.yrs + d0 + r16) * 4u;
+    // Lane (r16, q) of MFMA tile `it` holds local column tile_col(it, r16): tiles 0..3 interleave over the first 64
+    // columns (4*r16 + it) and tile 4 is the tail (64 + r16), so that ONE 16-byte load per lane feeds tiles 0..3 and
+    // one dword load tile 4 -- 4 vector-memory instructions per reduction step instead of 10, all of them whole
+    // 256-B / 64-B row segments.  Columns >= D (general shapes) get the out-of-range offset and read as 0.
+    constexpr unsigned OOB = 0x80000000u;
+    const unsigned vx4 = (EXACT || k0 + 4 * r16 < D) ? (unsigned)((long)q * p.xrs + k0 + 4 * r16) * 4u : OOB;
+    const unsigned vx1 = (EXACT || k0 + 64 + r16 < D) ? (unsigned)((long)q * p.xrs + k0 + 64 + r16) * 4u : OOB;
+    const unsigned vy4 = (EXACT || d0 + 4 * r16 < D) ? (unsigned)((long)q * p.yrs + d0 + 4 * r16) * 4u : OOB;
+    const unsigned vy1 = (EXACT || d0 + 64 + r16 < D) ? (unsigned)((long)q * p.yrs + d0 + 64 + r16) * 4u : OOB;
     const unsigned xbytes = (unsigned)(((long)(R - 1) * p.xrs + D) * 4);
     const unsigned ybytes = (unsigned)(((long)(R - 1) * p.yrs + D) * 4);
     const int xstep = (int)(p.xrs * 16), ystep = (int)(p.yrs * 16);
-    unsigned mA[EXACT ? 1 : KT], mB[EXACT ? 1 : DT];
-    if (!EXACT) {
-#pragma unroll
-        for (int it = 0; it < KT; ++it) mA[it] = k0 + 16 * it + r16 < D ? 0xffffffffu : 0u;
-#pragma unroll
-        for (int jt = 0; jt < DT; ++jt) mB[jt] = d0 + 16 * jt + r16 < D ? 0xffffffffu : 0u;
-    }
 
     float a0[KT], b0[DT], a1[KT], b1[DT];
     __amdgpu_buffer_rsrc_t rx, ry, rxn, ryn;                           // current / next group
@@ -415,22 +426,22 @@ __global__ __launch_bounds__(256, 2) void bwd_e_pipe_kernel(const BwdEParams p) 
     bool diag_first = true;
     auto load_step = [&](__amdgpu_buffer_rsrc_t dx, __amdgpu_buffer_rsrc_t dy, float (&a)[KT], float (&b)[DT], int s) {
         if (NRM_DIAG_NOLOAD == 1 && !(diag_first && s < 2)) return;
+        const u32x4 va = __builtin_amdgcn_raw_buffer_load_b128(dx, vx4, s * xstep, 0);
+        const u32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(dy, vy4, s * ystep, 0);
 #pragma unroll
-        for (int it = 0; it < KT; ++it) {
-            const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(dx, vx + 64 * it, s * xstep, 0);
-            a[it] = __uint_as_float(EXACT ? v : (v & mA[it]));
-        }
-#pragma unroll
-        for (int jt = 0; jt < DT; ++jt) {
-            const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(dy, vy + 64 * jt, s * ystep, 0);
-            b[jt] = __uint_as_float(EXACT ? v : (v & mB[jt]));
-        }
+        for (int e = 0; e < 4; ++e) { a[e] = __uint_as_float(va[e]); b[e] = __uint_as_float(vb[e]); }
+        if (KT > 4) a[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dx, vx1, s * xstep, 0));
+        if (DT > 4) b[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dy, vy1, s * ystep, 0));
     };
     auto mfma_batch = [&](f32x4 (&E)[KT][DT], const float (&a)[KT], const float (&b)[DT]) {
 #pragma unroll
+        for (int it = 0; it < 4; ++it)                                  // fed by the two 16-byte loads
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) E[it][jt] = mfma16(a[it], b[jt], E[it][jt]);
+#pragma unroll
         for (int it = 0; it < KT; ++it)
 #pragma unroll
-            for (int jt = 0; jt < DT; ++jt) E[it][jt] = mfma16(a[it], b[jt], E[it][jt]);
+            for (int jt = (it < 4 ? 4 : 0); jt < DT; ++jt) E[it][jt] = mfma16(a[it], b[jt], E[it][jt]);
     };
     // epilogue slice: d tile jt of a finished accumulator set -> bounce[16*jt .. 16*jt+15]
     auto slice = [&](const f32x4 (&E)[KT][DT], int jt) {
@@ -443,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void bwd_e_pipe_kernel(const BwdEParams p) 
             acc = fmaf(w4[0], e4[0], fmaf(w4[1], e4[1], fmaf(w4[2], e4[2], fmaf(w4[3], e4[3], acc))));
         }
         acc = sum_rows4(acc);
-        if (q == 0) bounce[dl] = acc;
+        if (q == 0) bounce[tile_col(jt, r16)] = acc;
     };
     auto flush = [&](int grow) {
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
@@ -466,9 +477,13 @@ __global__ __launch_bounds__(256, 2) void bwd_e_pipe_kernel(const BwdEParams p) 
         for (int s = 0; s < PE; ++s) {                                  // nsteps >= PE + 2: loads stay in group g
             if (s == 0 && !NRM_DIAG_NOEPI) {                            // C = inline 0: no accumulator clearing
 #pragma unroll
+                for (int it = 0; it < 4; ++it)
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) Ec[it][jt] = mfma16(a0[it], b0[jt], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
                 for (int it = 0; it < KT; ++it)
 #pragma unroll
-                    for (int jt = 0; jt < DT; ++jt) Ec[it][jt] = mfma16(a0[it], b0[jt], f32x4{0.f, 0.f, 0.f, 0.f});
+                    for (int jt = (it < 4 ? 4 : 0); jt < DT; ++jt) Ec[it][jt] = mfma16(a0[it], b0[jt], f32x4{0.f, 0.f, 0.f, 0.f});
                 load_step(rx, ry, a0, b0, 2);
             }
             else if (s & 1) { mfma_batch(Ec, a1, b1); load_step(rx, ry, a1, b1, s + 2); }
