@@ -223,59 +223,83 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTnParams p) {
         const_cast<float*>(p.A) + (size_t)r_lo * p.lda, 0, nrows > 0 ? ((nrows - 1) * p.lda + p.acols) * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.B) + (size_t)r_lo * p.ldb, 0, nrows > 0 ? ((nrows - 1) * p.ldb + p.bcols) * 4 : 0, 0x00020000);
-    const unsigned va = (unsigned)(q * p.lda + i0 + r16) * 4u;
-    const unsigned vb = (unsigned)(q * p.ldb + j0 + r16) * 4u;
+    // Column layout as in the backward contractions (pwattn_bwd.hip, tile_col): lane (r16, q) holds columns
+    // 4*r16 + tile of tiles 0..3 and column 64 + r16 of tile 4, so one 16-byte load per lane feeds four MFMA operands
+    // (2 + 2 vector-memory instructions per reduction step instead of 5 + 5).
+    const unsigned va4 = (unsigned)(q * p.lda + i0 + 4 * r16) * 4u, va1 = (unsigned)(q * p.lda + i0 + 64 + r16) * 4u;
+    const unsigned vb4 = (unsigned)(q * p.ldb + j0 + 4 * r16) * 4u, vb1 = (unsigned)(q * p.ldb + j0 + 64 + r16) * 4u;
     const int astep = p.lda * 16, bstep = p.ldb * 16;
 
     f32x4 C[KT][DT];
-#pragma unroll
-    for (int it = 0; it < KT; ++it)
-#pragma unroll
-        for (int jt = 0; jt < DT; ++jt) C[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float cs[KT];
 #pragma unroll
     for (int it = 0; it < KT; ++it) cs[it] = 0.f;
 
-    float a0[KT], b0[DT], a1[KT], b1[DT];
+    // four operand register sets: operands are requested three reduction steps ahead of their MFMAs
+    float a0[KT], b0[DT], a1[KT], b1[DT], a2[KT], b2[DT], a3[KT], b3[DT];
     auto load_step = [&](float (&a)[KT], float (&b)[DT], int s) {
+        const u32x4 xa = __builtin_amdgcn_raw_buffer_load_b128(ra, va4, s * astep, 0);
+        const u32x4 xb = __builtin_amdgcn_raw_buffer_load_b128(rb, vb4, s * bstep, 0);
 #pragma unroll
-        for (int it = 0; it < KT; ++it) a[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, va + 64 * it, s * astep, 0));
-#pragma unroll
-        for (int jt = 0; jt < DT; ++jt) b[jt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, vb + 64 * jt, s * bstep, 0));
+        for (int e = 0; e < 4; ++e) { a[e] = __uint_as_float(xa[e]); b[e] = __uint_as_float(xb[e]); }
+        if (KT > 4) a[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, va1, s * astep, 0));
+        if (DT > 4) b[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, vb1, s * bstep, 0));
     };
     auto mfma_batch = [&](const float (&a)[KT], const float (&b)[DT]) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)                                  // fed by the two 16-byte loads
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) C[it][jt] = mfma16(a[it], b[jt], C[it][jt]);
 #pragma unroll
         for (int it = 0; it < KT; ++it) {
             cs[it] += a[it];
 #pragma unroll
-            for (int jt = 0; jt < DT; ++jt) C[it][jt] = mfma16(a[it], b[jt], C[it][jt]);
+            for (int jt = (it < 4 ? 4 : 0); jt < DT; ++jt) C[it][jt] = mfma16(a[it], b[jt], C[it][jt]);
         }
     };
-    if (nsteps > 0) load_step(a0, b0, 0);
-    for (int s = 0; s < nsteps; s += 2) {
-        if (s + 1 < nsteps) load_step(a1, b1, s + 1);
+#pragma unroll
+    for (int it = 0; it < KT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < DT; ++jt) C[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (0 < nsteps) load_step(a0, b0, 0);
+    if (1 < nsteps) load_step(a1, b1, 1);
+    if (2 < nsteps) load_step(a2, b2, 2);
+    for (int s = 0; s < nsteps; s += 4) {
+        if (s + 3 < nsteps) load_step(a3, b3, s + 3);
         mfma_batch(a0, b0);
         if (s + 1 < nsteps) {
-            if (s + 2 < nsteps) load_step(a0, b0, s + 2);
+            if (s + 4 < nsteps) load_step(a0, b0, s + 4);
             mfma_batch(a1, b1);
+        }
+        if (s + 2 < nsteps) {
+            if (s + 5 < nsteps) load_step(a1, b1, s + 5);
+            mfma_batch(a2, b2);
+        }
+        if (s + 3 < nsteps) {
+            if (s + 6 < nsteps) load_step(a2, b2, s + 6);
+            mfma_batch(a3, b3);
         }
     }
 
+    // lane holds C[it][jt][e] = c[i0 + tile_col(it, 4q+e)][j0 + tile_col(jt, r16)]; the slab is transposed (ws[split][j][i])
     float* wsp = p.ws + (size_t)split * p.ncols_j * p.ldws;
 #pragma unroll
     for (int jt = 0; jt < DT; ++jt) {
-        const int j = j0 + 16 * jt + r16;
+        const int j = j0 + (jt < 4 ? 4 * r16 + jt : 64 + r16);
+        if (j >= p.ncols_j) continue;
+        float* row = wsp + (size_t)j * p.ldws + i0;
 #pragma unroll
-        for (int it = 0; it < KT; ++it) {
-            const int i = i0 + 16 * it + 4 * q;
-            if (j < p.ncols_j && i < p.ldws) *reinterpret_cast<f32x4*>(wsp + (size_t)j * p.ldws + i) = C[it][jt];
+        for (int e = 0; e < 4; ++e) {
+            const int ii = 16 * q + 4 * e;
+            if (i0 + ii < p.ldws) *reinterpret_cast<f32x4*>(row + ii) = f32x4{C[0][jt][e], C[1][jt][e], C[2][jt][e], C[3][jt][e]};
         }
+        if (KT > 4 && i0 + 64 + 4 * q < p.ldws) *reinterpret_cast<f32x4*>(row + 64 + 4 * q) = C[KT - 1][jt];
     }
     if (p.colsum && tj == 0) {
 #pragma unroll
         for (int it = 0; it < KT; ++it) {
             const float v = sum_rows4(cs[it]);
-            const int i = i0 + 16 * it + r16;
+            const int i = i0 + (it < 4 ? 4 * r16 + it : 64 + r16);
             if (q == 0 && i < p.ldws) p.colsum[(size_t)split * p.ldws + i] = v;
         }
     }

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Compact what scripts/collect_profiles.sh wrote under gpurun_out/final/ into the committed files under profiles/:
+kernel-stats CSV + summary, per-kernel PMC means, the HBM-traffic figures bench.py quotes, and the bench line.
+usage: python scripts/pmc_summary.py [tag]      (tag defaults to "final"; files are named r1_c3_*_<tag>)"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.chdir(ROOT)
+tag = sys.argv[1] if len(sys.argv) > 1 else "final"
+src = "gpurun_out/final"
+
+stats = glob.glob(f"{src}/stats/*/*_kernel_stats.csv")[0]
+shutil.copy(stats, f"profiles/r1_c3_bench_kernel_stats_{tag}.csv")
+summary = subprocess.run([sys.executable, "scripts/rocprof_summary.py", f"profiles/r1_c3_bench_kernel_stats_{tag}.csv", "7"],
+                         capture_output=True, text=True, check=True).stdout
+open(f"profiles/r1_c3_bench_kernel_stats_{tag}.summary.txt", "w").write(summary)
+print(summary)
+
+out = {}
+for leg in ("sq", "fetch", "write"):
+    path = glob.glob(f"{src}/{leg}/*/*_counter_collection.csv")[0]
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        if "nrm::" not in r["Kernel_Name"]:
+            continue
+        k = r["Kernel_Name"].split("(")[0].replace("void nrm::", "").replace("nrm::", "")
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, c in agg.items():
+        out.setdefault(k, {}).update({n: sum(v) / len(v) for n, v in c.items()})
+os.makedirs("profiles/pmc", exist_ok=True)
+json.dump(out, open(f"profiles/pmc/r1_c3_pmc_counters_{tag}.json", "w"), indent=1, sort_keys=True)
+
+
+def pick(prefix):
+    """the full-size instantiation of a kernel family = the one with the most MFMA-busy cycles (or fetch)"""
+    c = [k for k in out if k.startswith(prefix)]
+    return max(c, key=lambda k: (out[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), out[k].get("FETCH_SIZE", 0.0))) if c else None
+
+
+names = {"nrm_pwattn_fwd": pick("pwattn_fwd_kernel"), "nrm_pwattn_bwd_dz": pick("bwd_dz_kernel"),
+         "pwattn_bwd_e_bt": pick("bwd_e_kernel"), "pwattn_bwd_e_bh": pick("bwd_e_pipe_kernel") or pick("bwd_e_kernel")}
+traffic = {"_note": "rocprofv3 PMC (separate passes, scripts/collect_profiles.sh), C3-large (B=1024,H=50,T=30,D=400), mean per launch. "
+           "FETCH_SIZE/WRITE_SIZE are KB. Per MI355X_MICROARCH.md FETCH_SIZE under-reports wide (16 B/lane) coalesced streaming reads "
+           "by 2x on gfx950: corrected_bytes doubles FETCH for kernels whose bulk reads are 16 B/lane (forward: LDS-DMA dwordx4; dz: "
+           "float4 loads; the backward contractions since their operands come as 16-byte loads)."}
+for t, kn in names.items():
+    if kn is None:
+        continue
+    g = out[kn]
+    f, w = g.get("FETCH_SIZE", 0.0), g.get("WRITE_SIZE", 0.0)
+    traffic[t] = {"kernel": kn, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "corrected_bytes": (2 * f + w) * 1024,
+                  "mfma_busy_frac": g.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024 / max(g.get("GRBM_GUI_ACTIVE", 0.0) / 8, 1.0),
+                  "clock_GHz_times_ms": g.get("GRBM_GUI_ACTIVE", 0.0) / 8 / 1e6,
+                  "lds_bank_conflict_frac": g.get("SQ_LDS_BANK_CONFLICT", 0.0) / 256 / max(g.get("GRBM_GUI_ACTIVE", 0.0) / 8, 1.0)}
+    print(t, {k: (round(v, 4) if isinstance(v, float) else v) for k, v in traffic[t].items()})
+json.dump(traffic, open("profiles/r1_c3_pmc_traffic.json", "w"), indent=1)
+shutil.copy(f"{src}/bench.json", f"profiles/r1_c3_bench_{tag}.json")
+d = json.load(open(f"profiles/r1_c3_bench_{tag}.json"))
+print(d["value"], d["ms_per_step"], d["roofline"], d.get("cpu_baseline", {}).get("value"), d.get("pcie_inclusive"), d["fwd_auc_parity"])
