@@ -26,14 +26,19 @@ print(summary)
 out = {}
 for leg in ("sq", "fetch", "write"):
     path = glob.glob(f"{src}/{leg}/*/*_counter_collection.csv")[0]
+    rows = [r for r in csv.DictReader(open(path)) if "nrm::" in r["Kernel_Name"]]
+    name = lambda r: r["Kernel_Name"].split("(")[0].replace("void nrm::", "").replace("nrm::", "")   # noqa: E731
+    # the same instantiation is also launched on small shapes (parity probe, side GEMMs): keep the largest grid only
+    biggest = collections.defaultdict(int)
+    for r in rows:
+        biggest[name(r)] = max(biggest[name(r)], int(r["Grid_Size"]))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(path)):
-        if "nrm::" not in r["Kernel_Name"]:
-            continue
-        k = r["Kernel_Name"].split("(")[0].replace("void nrm::", "").replace("nrm::", "")
-        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for r in rows:
+        if int(r["Grid_Size"]) == biggest[name(r)]:
+            agg[name(r)][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, c in agg.items():
         out.setdefault(k, {}).update({n: sum(v) / len(v) for n, v in c.items()})
+        out[k]["full_size_launches_" + leg] = len(next(iter(c.values())))
 os.makedirs("profiles/pmc", exist_ok=True)
 json.dump(out, open(f"profiles/pmc/r1_c3_pmc_counters_{tag}.json", "w"), indent=1, sort_keys=True)
 
