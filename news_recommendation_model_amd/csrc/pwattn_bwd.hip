@@ -36,61 +36,109 @@ namespace nrm {
 // ---------------------------------------------------------------------------------------------
 // (1) one pass over z: dz in place, plus every reduction of dz that does not need a contraction
 //       du[b,h,k] = sum_t dz[b,t,h,k]     dv[b,t,k] = sum_h dz[b,t,h,k]     dw2[k] += sum ds*gelu(z)
-//     workgroup = (one impression b) x (one slab of 128 columns); blockDim = (32 float4 columns, 8 rows).
-//     dv is a register sum over the inner h loop; du lives in LDS [H][128] (every (h, column) cell is
-//     owned by exactly one thread: h % 8 == ty), so z/dz are touched exactly once (HBM-bound kernel).
+//     HBM-bound (read z, write dz: 4.9 GB at C3; a plain in-place torch mul_ over the same bytes takes 0.84 ms).
+//     workgroup = (one impression b) x (one slab of <= 128 columns, all slabs equally wide: 4 x 100 at D = 400); its
+//     256 threads are nx float4 columns x ny rows and sweep the impression's rows in memory order (ny consecutive
+//     history rows at a time, candidate after candidate; the sibling slabs sweep the same rows at the same time, so
+//     DRAM sees whole rows -- a variant in which every thread streamed its own candidate ran at 1.6 TB/s).
+//     All loads of one candidate are requested before any arithmetic.  dv is a register sum over the inner h loop
+//     plus one LDS exchange per candidate (double-buffered: one barrier); du lives in LDS [H][nx] (every cell is owned
+//     by exactly one thread: h % ny == ty), so z/dz are touched exactly once.
+constexpr int DZ_MAXIT = 5;      // history rows per thread and candidate held in registers (H <= DZ_MAXIT * ny per sweep)
+
 __global__ __launch_bounds__(256) void bwd_dz_kernel(float* __restrict__ z, const float* __restrict__ ds,
                                                      const float* __restrict__ w2, float* __restrict__ dw2,
                                                      float* __restrict__ du, float* __restrict__ dv,
-                                                     int T, int H, int D) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];       // [H][128] du slab | [8][32] float4 scratch
-    f32x4* du_l = reinterpret_cast<f32x4*>(sm);                     // [H][32] float4
-    f32x4* red = du_l + H * 32;                                     // [8][32]
-    const int tx = threadIdx.x, ty = threadIdx.y;
+                                                     int T, int H, int D, int slab_cols) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // [H][nx] du slab | 2 x [256] float4 exchange
+    const int nx = slab_cols >> 2, ny = 256 / nx;
+    f32x4* du_l = reinterpret_cast<f32x4*>(sm);
+    f32x4* red = du_l + H * nx;
+    const int tid = threadIdx.x;
+    const int ty = tid / nx, tx = tid - ty * nx;
     const int b = blockIdx.y;
-    const int col = blockIdx.x * 128 + 4 * tx;
-    const bool cok = col < D;                                        // D % 4 == 0
+    const int col = blockIdx.x * slab_cols + 4 * tx;
+    const bool cok = ty < ny && col < D;                             // D % 4 == 0
     const f32x4 w = cok ? *reinterpret_cast<const f32x4*>(w2 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int h = ty; h < H; h += 8) du_l[h * 32 + tx] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ty < ny)
+        for (int h = ty; h < H; h += ny) du_l[h * nx + tx] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 aw = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < T; ++t) {
+    // rows hb + u*ny (u < DZ_MAXIT) of candidate t: request everything, then compute -- and the requests of candidate
+    // t+1 go out before the arithmetic of candidate t (two register buffers, the t loop is unrolled by two)
+    auto load_rows = [&](int t, int hb, f32x4 (&zz)[DZ_MAXIT], float (&g)[DZ_MAXIT]) {
         const long row0 = ((long)b * T + t) * H;
-        f32x4 av = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (cok) {
-            for (int h = ty; h < H; h += 8) {
-                const float g = ds[row0 + h];
-                float* zr = z + (row0 + h) * D + col;
-                const f32x4 zz = *reinterpret_cast<const f32x4*>(zr);
+#pragma unroll
+        for (int u = 0; u < DZ_MAXIT; ++u) {
+            const int h = hb + u * ny;
+            const bool ok = cok && t < T && h < H;
+            g[u] = ok ? ds[row0 + h] : 0.f;
+            zz[u] = ok ? *reinterpret_cast<const f32x4*>(z + (row0 + h) * D + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto compute_rows = [&](int t, int hb, const f32x4 (&zz)[DZ_MAXIT], const float (&g)[DZ_MAXIT], f32x4& av) {
+        const long row0 = ((long)b * T + t) * H;
+#pragma unroll
+        for (int u = 0; u < DZ_MAXIT; ++u) {
+            const int h = hb + u * ny;
+            if (cok && h < H) {
                 f32x4 dz;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const GeluParts gp = gelu_parts(zz[e]);
-                    aw[e] = fmaf(g * zz[e], gp.cdf, aw[e]);                          // ds * gelu(z)
-                    dz[e] = g * w[e] * fmaf(zz[e] * 0.39894228040143267794f, gp.e, gp.cdf);
+                    const GeluParts gp = gelu_parts(zz[u][e]);
+                    aw[e] = fmaf(g[u] * zz[u][e], gp.cdf, aw[e]);                          // ds * gelu(z)
+                    dz[e] = g[u] * w[e] * fmaf(zz[u][e] * 0.39894228040143267794f, gp.e, gp.cdf);
                 }
-                *reinterpret_cast<f32x4*>(zr) = dz;
+                *reinterpret_cast<f32x4*>(z + (row0 + h) * D + col) = dz;
                 av += dz;
-                du_l[h * 32 + tx] += dz;
+                du_l[h * nx + tx] += dz;
             }
         }
-        red[ty * 32 + tx] = av;
+    };
+    auto finish = [&](int t, const f32x4& av) {
+        f32x4* ex = red + (t & 1) * 256;                             // double-buffered: one barrier per candidate
+        ex[tid] = av;
         __syncthreads();
         if (ty == 0 && cok) {
-            f32x4 sum = red[tx];
-#pragma unroll
-            for (int y = 1; y < 8; ++y) sum += red[y * 32 + tx];
+            f32x4 sum = ex[tx];
+            for (int y = 1; y < ny; ++y) sum += ex[y * nx + tx];
             *reinterpret_cast<f32x4*>(dv + ((long)b * T + t) * D + col) = sum;
         }
-        __syncthreads();
+    };
+    const bool one_sweep = H <= DZ_MAXIT * ny;                       // the usual case: a candidate's rows fit one sweep
+    f32x4 zA[DZ_MAXIT], zB[DZ_MAXIT];
+    float gA[DZ_MAXIT], gB[DZ_MAXIT];
+    if (one_sweep) {
+        load_rows(0, ty, zA, gA);
+        for (int t = 0; t < T; t += 2) {
+            load_rows(t + 1, ty, zB, gB);
+            f32x4 av = f32x4{0.f, 0.f, 0.f, 0.f};
+            compute_rows(t, ty, zA, gA, av);
+            finish(t, av);
+            if (t + 1 < T) {
+                load_rows(t + 2, ty, zA, gA);
+                f32x4 av1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                compute_rows(t + 1, ty, zB, gB, av1);
+                finish(t + 1, av1);
+            }
+        }
+    } else {
+        for (int t = 0; t < T; ++t) {
+            f32x4 av = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int hb = ty; hb < H; hb += DZ_MAXIT * ny) {
+                load_rows(t, hb, zA, gA);
+                compute_rows(t, hb, zA, gA, av);
+            }
+            finish(t, av);
+        }
     }
     if (cok)
-        for (int h = ty; h < H; h += 8) *reinterpret_cast<f32x4*>(du + ((long)b * H + h) * D + col) = du_l[h * 32 + tx];
-    red[ty * 32 + tx] = aw;
+        for (int h = ty; h < H; h += ny) *reinterpret_cast<f32x4*>(du + ((long)b * H + h) * D + col) = du_l[h * nx + tx];
+    __syncthreads();
+    red[tid] = aw;
     __syncthreads();
     if (ty == 0 && cok) {
         f32x4 sum = red[tx];
-#pragma unroll
-        for (int y = 1; y < 8; ++y) sum += red[y * 32 + tx];
+        for (int y = 1; y < ny; ++y) sum += red[y * nx + tx];
 #pragma unroll
         for (int e = 0; e < 4; ++e) atomicAdd(dw2 + col + e, sum[e]);
     }
@@ -99,13 +147,16 @@ __global__ __launch_bounds__(256) void bwd_dz_kernel(float* __restrict__ z, cons
 hipError_t bwd_dz_launch(float* z, const float* ds, const float* w2, float* dw2, float* du, float* dv,
                          int B, int T, int H, int D, hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    const size_t shm = ((size_t)H * 32 + 8 * 32) * sizeof(f32x4);
+    const int nslab = (D + 127) / 128;
+    const int slab_cols = ((D + nslab - 1) / nslab + 3) / 4 * 4;     // equal slabs (D = 400: 4 x 100 columns)
+    const size_t shm = ((size_t)H * (slab_cols / 4) + 2 * 256) * sizeof(f32x4);
     if (shm > 160 * 1024) return hipErrorInvalidValue;
     if (shm > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)bwd_dz_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(bwd_dz_kernel, dim3((D + 127) / 128, B), dim3(32, 8), shm, st, z, ds, w2, dw2, du, dv, T, H, D);
+    hipLaunchKernelGGL(bwd_dz_kernel, dim3((D + slab_cols - 1) / slab_cols, B), dim3(256), shm, st, z, ds, w2, dw2, du, dv,
+                       T, H, D, slab_cols);
     return hipGetLastError();
 }
 
