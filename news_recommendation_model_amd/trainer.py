@@ -266,3 +266,41 @@ class BatchPrefetcher:
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         self.free[slot] = ev
+
+
+def train_epochs(model, optimizer, make_loader, epochs, device="cuda", ckpt_path=None, on_batch=None):
+    """The epoch loop of reference train.py:52-100 around ``train_step``: every epoch re-reads ``param_groups[0]['lr']``
+    (:57), steps through ``make_loader()`` (an iterable of host batches, dict fields as in ``synth.make_batch``), keeps
+    the running loss and per-impression AUC averages the reference prints (:77-88, AUC on the device instead of a
+    host sklearn loop), and saves the state_dict without ``delta`` (:95-97).  The reference never steps its scheduler
+    (:99-100), so none is taken here.  Batches are staged through ``BatchPrefetcher``.
+    Returns one dict per epoch: lr, loss_avg, auc_avg, impressions."""
+    from . import evaluation
+    history = []
+    for epoch in range(epochs):
+        model.train()                                                  # :56
+        lr = optimizer.param_groups[0]["lr"]
+        loss_sum = torch.zeros((), dtype=torch.float64, device=device)
+        auc_sum = torch.zeros((), dtype=torch.float64, device=device)
+        bad_rows = torch.zeros((), dtype=torch.int64, device=device)
+        seen = 0
+        pf = BatchPrefetcher(make_loader(), device)
+        for i, (batch, slot) in enumerate(pf):
+            loss, out = train_step(model, optimizer, batch)
+            auc, _hit = evaluation.row_auc_top1(out, batch["label"])
+            pf.release(slot)
+            n = out.shape[0]
+            loss_sum += loss.double() * n                               # :82 total_loss += loss.item() * B
+            auc_sum += auc.double().sum()
+            bad_rows += (auc < 0).sum()                                 # one class in a row: roc_auc_score raises (:79)
+            seen += n
+            if on_batch is not None:
+                on_batch(epoch, i, loss, auc)
+        if int(bad_rows):                                               # checked once per epoch: no per-batch host sync
+            raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
+        rec = {"epoch": epoch, "lr": lr, "impressions": seen,
+               "loss_avg": float(loss_sum / max(seen, 1)), "auc_avg": float(auc_sum / max(seen, 1))}
+        history.append(rec)
+        if ckpt_path is not None:
+            evaluation.save_checkpoint(model, ckpt_path.format(epoch=epoch))
+    return history
