@@ -36,7 +36,7 @@ def test_train_step_matches_reference_fixture(lib, name):
     torch.cuda.synchronize()
     r = out.detach().cpu().numpy()
     assert rel_err(r, fx["r"]) < FWD_TOL
-    assert abs(float(loss) - float(fx["loss"])) < FWD_TOL * abs(float(fx["loss"]))
+    assert abs(float(loss.detach()) - float(fx["loss"])) < FWD_TOL * abs(float(fx["loss"]))
     assert rel_err(grabbed["inv"][0].detach().cpu().numpy(), fx["eu_H"]) < FWD_TOL
     assert rel_err(grabbed["inv"][1].detach().cpu().numpy(), fx["ec"]) < FWD_TOL
     # per-row AUC of the new r equals the reference's (train.py:77-80)
@@ -69,7 +69,7 @@ def test_eval_mode_uses_running_stats(lib):
         out = model(tb["x_history"], tb["x_target"], tb["x_global"])
         loss = model.loss(tb["user_id"], out, tb["label"])
     assert rel_err(out.cpu().numpy(), fx["r"]) < FWD_TOL
-    assert abs(float(loss) - float(fx["loss"])) < FWD_TOL * abs(float(fx["loss"]))
+    assert abs(float(loss.detach()) - float(fx["loss"])) < FWD_TOL * abs(float(fx["loss"]))
 
 
 def test_float32_and_float64_inputs_agree(lib):
