@@ -153,8 +153,8 @@ def train_step(model, optimizer, batch, reducer: FlatGradReducer | None = None, 
 
 class GraphedTrainStep:
     """The whole train.py:69-75 step captured once into a HIP graph and replayed (static shapes, static input
-    buffers).  Small shapes are launch-bound -- ~150 kernel launches and 12 ms of host time for < 1 ms of GPU work
-    at the reference's default dimensions -- and a replay is a single launch.  New data is copied INTO the tensors
+    buffers).  A replay is a single launch instead of ~600: 2-13 % faster than the eager step depending on the shape
+    (reference default dimensions: 3.1 -> 2.7 ms).  New data is copied INTO the tensors
     of ``batch`` before ``replay()``; ``loss`` / ``out`` are overwritten in place by every replay."""
 
     def __init__(self, model, optimizer, batch, alpha=0.95, warmup=3):
