@@ -15,6 +15,10 @@
 // MFMA orientation is "transposed": the MFMA row index is k, the MFMA column index is the data row m,
 // so every lane ends up holding 4 consecutive k of one row m -> float4 loads of u/v and float4 stores
 // of z.  All MFMA work is v_mfma_f32_16x16x4_f32 (exact f32).
+// timing diagnostics only (scripts/_diag/build_diag.sh): results are WRONG with any of them set
+#ifndef NRM_DIAG_FWD
+#define NRM_DIAG_FWD 0        // bit 0: no accumulator-init loads, bit 1: no K-chunk DMA after the first, bit 2: no z store,
+#endif                        // bit 3: no GELU / fc2 dot (plain sum instead)
 #include "common.hpp"
 #include "pwattn.hpp"
 
@@ -116,8 +120,11 @@ __global__ __launch_bounds__(256, 2) void pwattn_fwd_kernel(const FwdParams p) {
 #pragma unroll
             for (int it = 0; it < NT; ++it) {
                 const int kb = (kc0 + it * 16) * 4;                       // uniform byte offset of the tile
-                const f32x4 uu = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, voff_u[jt], kb, 0));
-                const f32x4 vv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, voff_v[jt], kb, 0));
+                f32x4 uu = f32x4{0.f, 0.f, 0.f, 0.f}, vv = uu;
+                if (!(NRM_DIAG_FWD & 1)) {
+                    uu = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, voff_u[jt], kb, 0));
+                    vv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, voff_v[jt], kb, 0));
+                }
                 const bool kok = kc0 + it * 16 + 4 * q < D;               // only matters when D % 16 != 0
                 acc[it][jt] = kok ? uu + vv : f32x4{0.f, 0.f, 0.f, 0.f};
                 // bound the burst (8 loads in flight): all 2*NT*MT at once would be the register peak of
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void pwattn_fwd_kernel(const FwdParams p) {
         for (int c = 0; c < p.kchunks; ++c) {
             float* cur = smem + (c & 1) * BUF;
             float* nxt = smem + ((c & 1) ^ 1) * BUF;
-            if (c + 1 < p.kchunks) dma_chunk(c + 1, nxt);
+            if (c + 1 < p.kchunks && !((NRM_DIAG_FWD & 2) && c > 0)) dma_chunk(c + 1, nxt);
             compute(cur);
             __syncthreads();
         }
@@ -186,11 +193,12 @@ __global__ __launch_bounds__(256, 2) void pwattn_fwd_kernel(const FwdParams p) {
 #pragma unroll
             for (int jt = 0; jt < MT; ++jt) {
                 const f32x4 zz = acc[it][jt];
-                if (SAVE_Z && kok) {
+                if (SAVE_Z && kok && !(NRM_DIAG_FWD & 4)) {
                     const unsigned vz = (unsigned)(((wave * MT + jt) * 16 + r16) * D + 4 * q) * 4u;   // rows >= M: out of range
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zz), rs_z, vz, kb, 0);
                 }
-                s_part[jt] += ww[0] * gelu_f(zz[0]) + ww[1] * gelu_f(zz[1]) + ww[2] * gelu_f(zz[2]) + ww[3] * gelu_f(zz[3]);
+                if (NRM_DIAG_FWD & 8) s_part[jt] += ww[0] * zz[0] + ww[1] * zz[1] + ww[2] * zz[2] + ww[3] * zz[3];
+                else s_part[jt] += ww[0] * gelu_f(zz[0]) + ww[1] * gelu_f(zz[1]) + ww[2] * gelu_f(zz[2]) + ww[3] * gelu_f(zz[3]);
             }
         }
     }
