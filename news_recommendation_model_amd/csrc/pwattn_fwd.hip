@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void pwattn_fwd_kernel(const FwdParams p) {
 // Up to 25 column tiles (D <= 400) the whole width is ONE N-chunk: no column padding and a single
 // accumulator-init / epilogue per row tile (measured at D=400: 13x3 in two chunks 4.73 ms, 25x1 4.28 ms).
 static const int kNT[10] = {4, 6, 8, 10, 12, 13, 14, 16, 20, 25};
-static const int kMT[10] = {4, 4, 3, 3, 3, 3, 2, 2, 1, 1};
+static const int kMT[10] = {4, 4, 3, 3, 3, 3, 2, 1, 1, 1};
 
 FwdPlan pwattn_fwd_plan(int D) {
     const int n16 = (D + 15) / 16;
@@ -255,7 +255,7 @@ hipError_t pwattn_fwd_launch(const FwdParams& p, const FwdPlan& pl, hipStream_t 
         case 12: return launch_fwd_t<12, 3>(p, st);
         case 13: return launch_fwd_t<13, 3>(p, st);
         case 14: return launch_fwd_t<14, 2>(p, st);
-        case 16: return launch_fwd_t<16, 2>(p, st);
+        case 16: return launch_fwd_t<16, 1>(p, st);
         case 20: return launch_fwd_t<20, 1>(p, st);
         case 25: return launch_fwd_t<25, 1>(p, st);
     }
