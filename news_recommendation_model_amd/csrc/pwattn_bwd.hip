@@ -347,12 +347,16 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
 #pragma unroll
         for (int jt = 0; jt < DT; ++jt) {
             const int dl = 16 * jt + r16;
+            f32x4 w4[KT];                                                // the column's five LDS reads go out together:
+#pragma unroll
+            for (int it = 0; it < KT; ++it)                              // one latency per column instead of one per read
+                w4[it] = *reinterpret_cast<const f32x4*>(&wpt[dl * LDK + 16 * it + 4 * q]);
+            __builtin_amdgcn_sched_barrier(0);
             float acc = 0.f;
 #pragma unroll
             for (int it = 0; it < KT; ++it) {
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(&wpt[dl * LDK + 16 * it + 4 * q]);
                 const f32x4 e4 = E[it][jt];
-                acc = fmaf(w4[0], e4[0], fmaf(w4[1], e4[1], fmaf(w4[2], e4[2], fmaf(w4[3], e4[3], acc))));
+                acc = fmaf(w4[it][0], e4[0], fmaf(w4[it][1], e4[1], fmaf(w4[it][2], e4[2], fmaf(w4[it][3], e4[3], acc))));
                 if (WITH_DW) dW[it][jt] += e4 * sr[jt];
             }
             acc = sum_rows4(acc);
@@ -497,12 +501,14 @@ __global__ __launch_bounds__(256, 2) void bwd_e_pipe_kernel(const BwdEParams p) 
     // epilogue slice: d tile jt of a finished accumulator set -> bounce[16*jt .. 16*jt+15]
     auto slice = [&](const f32x4 (&E)[KT][DT], int jt) {
         const int dl = 16 * jt + r16;
+        f32x4 w4[KT];                                                    // the five LDS reads of the column go out together
+#pragma unroll
+        for (int it = 0; it < KT; ++it) w4[it] = *reinterpret_cast<const f32x4*>(&wpt[dl * LDK + 16 * it + 4 * q]);
         float acc = 0.f;
 #pragma unroll
         for (int it = 0; it < KT; ++it) {
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>(&wpt[dl * LDK + 16 * it + 4 * q]);
             const f32x4 e4 = E[it][jt];
-            acc = fmaf(w4[0], e4[0], fmaf(w4[1], e4[1], fmaf(w4[2], e4[2], fmaf(w4[3], e4[3], acc))));
+            acc = fmaf(w4[it][0], e4[0], fmaf(w4[it][1], e4[1], fmaf(w4[it][2], e4[2], fmaf(w4[it][3], e4[3], acc))));
         }
         acc = sum_rows4(acc);
         if (q == 0) bounce[tile_col(jt, r16)] = acc;
