@@ -14,7 +14,7 @@ Extra objects on the line:
                 launch (2*B*T*H*D^2, the contraction only) / its mean launch duration measured
                 with HIP events on the launch stream, against the dense fp32 MFMA peak of gfx950.  Inside the timed
                 region only the four big attention kernels are bracketed by events; the rest of the `kernels`
-                table is measured on the last 3 warm-up steps (an event pair per launch on all ~600 launches of a
+                table is measured on 3 extra untimed steps after the warm-up (an event pair per launch on all ~600 launches of a
                 step costs 1.5 % at C3 and 3-4x on the small shapes).
   cpu_baseline  the oracle (PyTorch-CPU restatement of the reference-literal algorithm) timed on this box's
                 host cores on a bounded sample of the same workload (reduced B), rank 0, N=1 only.
@@ -214,14 +214,14 @@ def main():
             loss, _ = run()
         sync()
     else:
-        # the full per-kernel table comes from 3 eager steps outside the timed region; inside it only the four big
+        # the full per-kernel table comes from 3 extra eager steps outside the timed region; inside it only the four big
         # attention kernels (the roofline candidates, 8 launches per step) are bracketed by events -- bracketing all
         # ~600 launches of a step costs 1.5 % at C3 and 3-4x on the small shapes
-        for _ in range(max(args.warmup - 3, 0)):
+        for _ in range(args.warmup):
             trainer.train_step(model, opt, tb, reducer)
         sync()
         native.kernel_events = []
-        for _ in range(min(3, args.warmup)):
+        for _ in range(3):                         # table steps: untimed, after the W warm-up steps
             trainer.train_step(model, opt, tb, reducer)
         sync()
         table_events = native.kernel_events

@@ -45,7 +45,7 @@ int nrm_pwattn_fwd(const float* t, const float* h, const float* u, const float* 
 /* backward, step 1 (autograd of attention_model.py:29-32 through GELU and fc2), one pass over z:
  *   z <- dz = ds * w2 * gelu'(z) in place;  dw2[k] += sum ds*gelu(z)   (dw2 must be initialised)
  *   du[b,h,:] = sum_t dz[b,t,h,:]  (gradient of u)      dv[b,t,:] = sum_h dz[b,t,h,:]  (gradient of v)
- * ds [B,T,H]; du [B,H,D] and dv [B,T,D] are overwritten.  H <= 300. */
+ * ds [B,T,H]; du [B,H,D] and dv [B,T,D] are overwritten (histories longer than 256 rows are processed in chunks). */
 int nrm_pwattn_bwd_dz(float* z_inout, const float* ds, const float* w2, float* dw2, float* du, float* dv,
                       int B, int T, int H, int D, nrm_stream_t stream);
 /* number of [D,D] partial slabs nrm_pwattn_bwd_contract writes into `ws` */

@@ -86,7 +86,7 @@ int nrm_pwattn_bwd_dz(float* z_inout, const float* ds, const float* w2, float* d
                       int B, int T, int H, int D, nrm_stream_t stream) {
     if (int rc = check_dims("nrm_pwattn_bwd_dz", B, T, H, D)) return rc;
     if (!z_inout || !ds || !w2 || !dw2 || !du || !dv) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dz: null pointer");
-    if (H > 300) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dz: H=%d > 300 (the du slab must fit the 160 KB LDS)", H);
+    if (B > 65535) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dz: B=%d > 65535 (one grid row per impression)", B);
     return check_hip(nrm::bwd_dz_launch(z_inout, ds, w2, dw2, du, dv, B, T, H, D, (hipStream_t)stream), "bwd_dz");
 }
 

@@ -49,9 +49,14 @@ constexpr int DZ_MAXIT = 5;      // history rows per thread and candidate held i
 __global__ __launch_bounds__(256) void bwd_dz_kernel(float* __restrict__ z, const float* __restrict__ ds,
                                                      const float* __restrict__ w2, float* __restrict__ dw2,
                                                      float* __restrict__ du, float* __restrict__ dv,
-                                                     int T, int H, int D, int slab_cols) {
+                                                     int T, int Hall, int D, int slab_cols, int hchunk) {
     extern __shared__ __attribute__((aligned(16))) float sm[];       // [H][nx] du slab | 2 x [256] float4 exchange
     const int nx = slab_cols >> 2, ny = 256 / nx;
+    // blockIdx.z = chunk of history rows [h0, h0 + H): one chunk unless the du slab of all rows would not fit the LDS
+    // (H > 256); with several chunks dv is accumulated across them with float atomics (the launcher zeroes it)
+    const int h0 = blockIdx.z * hchunk;
+    const int H = min(hchunk, Hall - h0);
+    const bool dv_atomic = gridDim.z > 1;
     f32x4* du_l = reinterpret_cast<f32x4*>(sm);
     f32x4* red = du_l + H * nx;
     const int tid = threadIdx.x;
@@ -66,7 +71,7 @@ __global__ __launch_bounds__(256) void bwd_dz_kernel(float* __restrict__ z, cons
     // rows hb + u*ny (u < DZ_MAXIT) of candidate t: request everything, then compute -- and the requests of candidate
     // t+1 go out before the arithmetic of candidate t (two register buffers, the t loop is unrolled by two)
     auto load_rows = [&](int t, int hb, f32x4 (&zz)[DZ_MAXIT], float (&g)[DZ_MAXIT]) {
-        const long row0 = ((long)b * T + t) * H;
+        const long row0 = ((long)b * T + t) * Hall + h0;
 #pragma unroll
         for (int u = 0; u < DZ_MAXIT; ++u) {
             const int h = hb + u * ny;
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(256) void bwd_dz_kernel(float* __restrict__ z, cons
         }
     };
     auto compute_rows = [&](int t, int hb, const f32x4 (&zz)[DZ_MAXIT], const float (&g)[DZ_MAXIT], f32x4& av) {
-        const long row0 = ((long)b * T + t) * H;
+        const long row0 = ((long)b * T + t) * Hall + h0;
 #pragma unroll
         for (int u = 0; u < DZ_MAXIT; ++u) {
             const int h = hb + u * ny;
@@ -101,7 +106,11 @@ __global__ __launch_bounds__(256) void bwd_dz_kernel(float* __restrict__ z, cons
         if (ty == 0 && cok) {
             f32x4 sum = ex[tx];
             for (int y = 1; y < ny; ++y) sum += ex[y * nx + tx];
-            *reinterpret_cast<f32x4*>(dv + ((long)b * T + t) * D + col) = sum;
+            float* dvp = dv + ((long)b * T + t) * D + col;
+            if (!dv_atomic) *reinterpret_cast<f32x4*>(dvp) = sum;
+            else
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(dvp + e, sum[e]);
         }
     };
     const bool one_sweep = H <= DZ_MAXIT * ny;                       // the usual case: a candidate's rows fit one sweep
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(256) void bwd_dz_kernel(float* __restrict__ z, cons
         }
     }
     if (cok)
-        for (int h = ty; h < H; h += ny) *reinterpret_cast<f32x4*>(du + ((long)b * H + h) * D + col) = du_l[h * nx + tx];
+        for (int h = ty; h < H; h += ny) *reinterpret_cast<f32x4*>(du + ((long)b * Hall + h0 + h) * D + col) = du_l[h * nx + tx];
     __syncthreads();
     red[tid] = aw;
     __syncthreads();
@@ -149,14 +158,20 @@ hipError_t bwd_dz_launch(float* z, const float* ds, const float* w2, float* dw2,
     if (B <= 0) return hipSuccess;
     const int nslab = (D + 127) / 128;
     const int slab_cols = ((D + nslab - 1) / nslab + 3) / 4 * 4;     // equal slabs (D = 400: 4 x 100 columns)
-    const size_t shm = ((size_t)H * (slab_cols / 4) + 2 * 256) * sizeof(f32x4);
-    if (shm > 160 * 1024) return hipErrorInvalidValue;
+    const int hchunk = H <= 256 ? H : 256;                           // history rows whose du slab shares the LDS
+    const int nhc = (H + hchunk - 1) / hchunk;
+    const size_t shm = ((size_t)hchunk * (slab_cols / 4) + 2 * 256) * sizeof(f32x4);
+    if (shm > 160 * 1024 || nhc > 65535) return hipErrorInvalidValue;
     if (shm > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)bwd_dz_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(bwd_dz_kernel, dim3((D + slab_cols - 1) / slab_cols, B), dim3(256), shm, st, z, ds, w2, dw2, du, dv,
-                       T, H, D, slab_cols);
+    if (nhc > 1) {                                                    // dv is summed over the history chunks
+        hipError_t e = hipMemsetAsync(dv, 0, (size_t)B * T * D * sizeof(float), st);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(bwd_dz_kernel, dim3((D + slab_cols - 1) / slab_cols, B, nhc), dim3(256), shm, st, z, ds, w2, dw2, du, dv,
+                       T, H, D, slab_cols, hchunk);
     return hipGetLastError();
 }
 
