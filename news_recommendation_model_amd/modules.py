@@ -43,9 +43,9 @@ class MLP(nn.Module):
     def forward(self, x):
         ops._require_gpu(x)
         if isinstance(self.activation, nn.GELU) and self.activation.approximate == "none":
-            hidden = ops.linear(x, self.fc1.weight, self.fc1.bias, gelu=True)      # fused bias + exact GELU
-        else:
-            hidden = self.activation(ops.linear(x, self.fc1.weight, self.fc1.bias))
+            # one autograd node: bias + exact GELU fused into fc1's GEMM, GELU' fused into the backward GEMM of fc2
+            return ops.mlp_gelu(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+        hidden = self.activation(ops.linear(x, self.fc1.weight, self.fc1.bias))
         return ops.linear(hidden, self.fc2.weight, self.fc2.bias)
 
 

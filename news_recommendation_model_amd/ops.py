@@ -220,6 +220,55 @@ def linear(x, weight, bias=None, gelu=False):
     return y.reshape(*lead, weight.shape[0])
 
 
+class _MlpGelu(torch.autograd.Function):
+    """fc2(gelu(fc1(x))) for a 2-D x (reference models/attention_model.py:29-32 with the default activation) as ONE
+    autograd node: forward = two GEMMs (bias + exact GELU fused into the first, its pre-activation saved); backward =
+    dW2/db2, then d(pre-activation) = (dY W2) * gelu'(z) with the GELU derivative fused into that GEMM's epilogue
+    (NRM_EPI_DGELU), then dW1/db1 and dX -- no elementwise pass over the hidden activations in either direction."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        _require_gpu(x, w1, w2)
+        x = _rows(x)
+        w1, w2 = _f32c(w1), _f32c(w2)
+        N1, K1 = w1.shape
+        N2, K2 = w2.shape
+        if x.shape[1] != K1 or K2 != N1:
+            raise RuntimeError(f"mlp: input has {x.shape[1]} features, fc1 expects {K1}, fc2 expects {K2} hidden")
+        hidden, z = _gemm_nt(x, w1, K1, 1, N1, K1, _f32c(b1) if b1 is not None else None, 1)
+        y, _ = _gemm_nt(hidden, w2, K2, 1, N2, K2, _f32c(b2) if b2 is not None else None, 0)
+        ctx.save_for_backward(x, w1, w2, hidden, z)
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, hidden, z = ctx.saved_tensors
+        N1, K1 = w1.shape
+        N2, K2 = w2.shape
+        dy = _rows(dy)
+        need = ctx.needs_input_grad
+        dw2 = db2 = dw1 = db1 = dx = None
+        if need[3] or (ctx.has_bias[1] and need[4]):
+            dw2, db2 = _gemm_tn(dy, hidden, ctx.has_bias[1])               # dW2[n,k] = sum_m dy[m,n] hidden[m,k]
+        # d(pre-activation of fc1) = (dY W2) * gelu'(z): epilogue 2 reads z and writes the product
+        dz, _ = _gemm_nt(dy, w2, 1, K2, K2, N2, None, 2, z=z)
+        if need[1] or (ctx.has_bias[0] and need[2]):
+            dw1, db1 = _gemm_tn(dz, x, ctx.has_bias[0])
+        if need[0]:
+            dx, _ = _gemm_nt(dz, w1, 1, K1, K1, N1, None, 0)
+        return dx, dw1, (db1 if ctx.has_bias[0] else None), dw2, (db2 if ctx.has_bias[1] else None)
+
+
+def mlp_gelu(x, fc1_weight, fc1_bias, fc2_weight, fc2_bias):
+    """Linear -> exact GELU -> Linear on the last dimension of x (one fused autograd node)."""
+    lead = x.shape[:-1]
+    if x.numel() == 0 and x.shape[-1] == fc1_weight.shape[1]:
+        return _degenerate((*lead, fc2_weight.shape[0]), x, fc1_weight, fc1_bias, fc2_weight, fc2_bias)
+    y = _MlpGelu.apply(x.reshape(-1, x.shape[-1]), fc1_weight, fc1_bias, fc2_weight, fc2_bias)
+    return y.reshape(*lead, fc2_weight.shape[0])
+
+
 # ------------------------------------------------------------------------------------------------ BatchNorm1d
 class _BatchNorm(torch.autograd.Function):
     @staticmethod

@@ -35,6 +35,32 @@ def test_linear_forward_backward(lib, M, K, N, gelu):
     assert rel_err(bg.grad.cpu().numpy(), br.grad.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("M,K,Hd,N", [(300, 1608, 402, 1608), (257, 1608, 402, 1), (64, 264, 66, 264), (33, 72, 18, 5),
+                                      (7, 16, 4, 3), (1000, 256, 64, 1)])
+def test_mlp_gelu_forward_backward(lib, M, K, Hd, N):
+    """fc2(gelu(fc1 x)) as one node (models/attention_model.py:29-32): values and all five gradients against float64
+    PyTorch; the backward goes through the GELU'-fused GEMM epilogue (NRM_EPI_DGELU)."""
+    from news_recommendation_model_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + 3 * K + 5 * Hd + 7 * N)
+    x = torch.randn(M, K, generator=g)
+    w1 = torch.randn(Hd, K, generator=g) / np.sqrt(K)
+    b1 = torch.randn(Hd, generator=g) * 0.1
+    w2 = torch.randn(N, Hd, generator=g) / np.sqrt(Hd)
+    b2 = torch.randn(N, generator=g) * 0.1
+    gy = torch.randn(M, N, generator=g)
+    ref = [t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    F = torch.nn.functional
+    y_ref = F.linear(F.gelu(F.linear(ref[0], ref[1], ref[2])), ref[3], ref[4])
+    y_ref.backward(gy.double())
+    dev = [t.cuda().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    y = ops.mlp_gelu(*dev)
+    y.backward(gy.cuda())
+    assert tuple(y.shape) == (M, N)
+    assert rel_err(y.detach().cpu().numpy(), y_ref.detach().numpy()) < 1e-5
+    for a, r, name in zip(dev, ref, ("x", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")):
+        assert rel_err(a.grad.cpu().numpy(), r.grad.numpy()) < 1e-5, name
+
+
 def test_linear_accepts_strided_and_3d_inputs(lib):
     from news_recommendation_model_amd import ops
     torch.manual_seed(0)
