@@ -2,7 +2,7 @@
 //
 // pool (reference models/user_invariant_interest_model.py:86-87):  pooled[b,t,:] = sum_h s[b,t,h] * h[b,h,:]
 //   bmm_rows_kernel   out[b,i,:] = sum_j W[b,i,j] * X[b,j,:]      (forward: W = s; backward dh: W = s^T, X = g)
-//   rowdot_kernel     ds[b,t,h]  = sum_d g[b,t,d] * h[b,h,d]      (one wave per (t,h) pair, shuffle reduction)
+//   rowdot_kernel     ds[b,t,h]  = sum_d g[b,t,d] * h[b,h,d]      (batched NT GEMM on the matrix cores)
 // loss (reference models/user_model.py:37-43):
 //   L = (1-alpha) * BCEmean(softmax_T(out), y) + alpha * BCEmean(softmax_T(out + delta[id]), y)
 //   loss_kernel: one wave per impression; softmax max/sum and the row reductions are wave shuffles; writes the
@@ -46,38 +46,74 @@ __global__ __launch_bounds__(64) void bmm_rows_kernel(const float* __restrict__ 
     }
 }
 
-// one wave per (b, t) row of g, looping over h; blockDim = 256 (4 waves)
+// ds[b,t,h] = sum_d g[b,t,d] h[b,h,d]: a small batched "NT" GEMM (per impression [T x D] x [H x D]^T) on the matrix cores.
+// One wave per (impression, tile of 16 candidates): it walks the feature dimension in chunks of 16 with ONE 16-byte load
+// per lane and operand row (lane (r16, q) holds columns 16c + 4q .. +3 of row r16, so MFMA e of a chunk contracts the
+// columns {16c + 4q + e}: any split of the reduction index over the MFMAs is fine as long as both operands use the same)
+// and keeps up to four 16-row history tiles of accumulators; rows / columns past the edge read as 0 through the buffer
+// descriptors.  The chunk after the current one is requested before the current MFMAs.
 __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ g, long gsb, int ldg,
                                                      const float* __restrict__ h, long hsb, int ldh,
-                                                     float* __restrict__ ds, int T, int H, int D) {
+                                                     float* __restrict__ ds, int B, int T, int H, int D) {
+#if defined(__HIP_DEVICE_COMPILE__)
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int b = blockIdx.y;
-    const int t = blockIdx.x * 4 + wave;
-    if (t >= T) return;
-    const float* gr = g + b * gsb + (long)t * ldg;
-    const float* hb = h + b * hsb;
-    f32x4 gv[4];                                     // up to 1024 columns per lane-strided float4
-    const int nv = (D + 255) / 256;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int ntt = (T + 15) >> 4;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= B * ntt) return;
+    const int b = tile / ntt, t0 = (tile - b * ntt) * 16;
+    const int trows = min(16, T - t0);
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g) + b * gsb + (long)t0 * ldg, 0, ((trows - 1) * ldg + D) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(h) + b * hsb, 0, ((H - 1) * ldh + D) * 4, 0x00020000);
+    const unsigned va = r16 < trows ? (unsigned)(r16 * ldg + 4 * q) * 4u : OOB;
+    const int nchunk = (D + 15) >> 4;
+    for (int h0 = 0; h0 < H; h0 += 64) {
+        unsigned vb[4];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int c = 256 * v + 4 * lane;
-        gv[v] = (v < nv && c < D) ? *reinterpret_cast<const f32x4*>(gr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    for (int hh = 0; hh < H; ++hh) {
-        const float* hr = hb + (long)hh * ldh;
-        float acc = 0.f;
+        for (int j = 0; j < 4; ++j) vb[j] = h0 + 16 * j + r16 < H ? (unsigned)((h0 + 16 * j + r16) * ldh + 4 * q) * 4u : OOB;
+        f32x4 acc[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int c = 256 * v + 4 * lane;
-            if (v < nv && c < D) {
-                const f32x4 x = *reinterpret_cast<const f32x4*>(hr + c);
-                acc += gv[v][0] * x[0] + gv[v][1] * x[1] + gv[v][2] * x[2] + gv[v][3] * x[3];
+        for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // columns >= D of the last chunk (D % 16 != 0): D % 4 == 0, so a lane's four columns are all in or all out
+        auto load_chunk = [&](int c, f32x4& a4, f32x4 (&b4)[4]) {
+            const bool ok = 16 * c + 4 * q < D;
+            a4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, ok ? va : OOB, c * 64, 0));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                b4[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, ok ? vb[j] : OOB, c * 64, 0));
+        };
+        auto mfma_chunk = [&](const f32x4& a4, const f32x4 (&b4)[4]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = mfma16(a4[e], b4[j][e], acc[j]);
+        };
+        f32x4 a0, a1, b0[4], b1[4];
+        load_chunk(0, a0, b0);
+        for (int c = 0; c < nchunk; c += 2) {
+            if (c + 1 < nchunk) load_chunk(c + 1, a1, b1);
+            mfma_chunk(a0, b0);
+            if (c + 1 < nchunk) {
+                if (c + 2 < nchunk) load_chunk(c + 2, a0, b0);
+                mfma_chunk(a1, b1);
             }
         }
-        acc = wave_sum64(acc);
-        if (lane == 0) ds[((long)b * T + t) * H + hh] = acc;
+        // lane holds acc[j][e] = ds[t0 + 4q + e][h0 + 16j + r16]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int hc = h0 + 16 * j + r16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int t = t0 + 4 * q + e;
+                if (t < T && hc < H) ds[((long)b * T + t) * H + hc] = acc[j][e];
+            }
+        }
     }
+#endif
 }
 
 hipError_t bmm_rows_launch(const float* W, long wsb, long wsi, long wsj, const float* X, long xsb, int ldx,
@@ -91,7 +127,8 @@ hipError_t bmm_rows_launch(const float* W, long wsb, long wsi, long wsj, const f
 hipError_t rowdot_launch(const float* g, long gsb, int ldg, const float* h, long hsb, int ldh, float* ds,
                          int B, int T, int H, int D, hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(rowdot_kernel, dim3((T + 3) / 4, B), dim3(256), 0, st, g, gsb, ldg, h, hsb, ldh, ds, T, H, D);
+    const long tiles = (long)B * ((T + 15) / 16);
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, g, gsb, ldg, h, hsb, ldh, ds, B, T, H, D);
     return hipGetLastError();
 }
 

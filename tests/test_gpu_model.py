@@ -120,7 +120,8 @@ def test_loss_kernel_matches_oracle_including_clamp(lib):
 def test_pool_kernels_match_bmm(lib):
     from news_recommendation_model_amd import ops
     torch.manual_seed(1)
-    for B, T, H, D in ((3, 5, 7, 64), (2, 30, 50, 400), (1, 9, 130, 100), (2, 3, 5, 30)):
+    for B, T, H, D in ((3, 5, 7, 64), (2, 30, 50, 400), (1, 9, 130, 100), (2, 3, 5, 30), (2, 17, 70, 36), (1, 33, 64, 20),
+                       (5, 16, 65, 132), (1, 1, 1, 4)):
         s = torch.randn(B, T, H, device="cuda", requires_grad=True)
         h = torch.randn(B, H, D, device="cuda", requires_grad=True)
         g = torch.randn(B, T, D, device="cuda")
