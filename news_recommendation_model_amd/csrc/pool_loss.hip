@@ -1,7 +1,7 @@
 // Small kernels around the attention: the un-normalised weighted pool and the training loss.  gfx950 only.
 //
 // pool (reference models/user_invariant_interest_model.py:86-87):  pooled[b,t,:] = sum_h s[b,t,h] * h[b,h,:]
-//   bmm_rows_kernel   out[b,i,:] = sum_j W[b,i,j] * X[b,j,:]      (forward: W = s; backward dh: W = s^T, X = g)
+//   bmm_rows_kernel   out[b,i,:] = sum_j W[b,i,j] * X[b,j,:]      (forward: W = s; backward dh: W = s^T, X = g; batched GEMM on the matrix cores)
 //   rowdot_kernel     ds[b,t,h]  = sum_d g[b,t,d] * h[b,h,d]      (batched NT GEMM on the matrix cores)
 // loss (reference models/user_model.py:37-43):
 //   L = (1-alpha) * BCEmean(softmax_T(out), y) + alpha * BCEmean(softmax_T(out + delta[id]), y)
@@ -13,37 +13,68 @@
 
 namespace nrm {
 
-// blockDim = 64: lane owns one float4 of columns; grid = (column slabs of 256, i tiles of 8, B)
-__global__ __launch_bounds__(64) void bmm_rows_kernel(const float* __restrict__ W, long wsb, long wsi, long wsj,
-                                                      const float* __restrict__ X, long xsb, int ldx,
-                                                      float* __restrict__ out, long osb, int ldo,
-                                                      int I, int J, int D, int accumulate) {
-    const int b = blockIdx.z;
-    const int i0 = blockIdx.y * 8;
-    const int col = blockIdx.x * 256 + 4 * threadIdx.x;
-    if (col >= D) return;                            // D % 4 == 0
+// out[b,i,:] = sum_j W[b,i,j] X[b,j,:]: a small batched GEMM on the matrix cores.  One wave per (impression, 64-column
+// slab, group of up to four 16-row tiles of i): MFMA rows = i (A operand W[i][j], any strides: one dword per lane),
+// MFMA columns = the slab's columns in the interleaved order of the backward contractions (lane r16 holds columns
+// 4*r16 + tile of the four column tiles), so ONE 16-byte load of X[j][4*r16 .. +3] feeds four MFMAs and a lane's four
+// results of one output row are consecutive columns (float4 store).  Rows / columns past the edge read as 0.
+__global__ __launch_bounds__(256) void bmm_rows_kernel(const float* __restrict__ W, long wsb, long wsi, long wsj,
+                                                       const float* __restrict__ X, long xsb, int ldx,
+                                                       float* __restrict__ out, long osb, int ldo,
+                                                       int B, int I, int J, int D, int accumulate) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int nslab = (D + 63) >> 6, nig = (I + 63) >> 6;
+    const long task = (long)blockIdx.x * 4 + wave;
+    if (task >= (long)B * nslab * nig) return;
+    const int slab = (int)(task % nslab);
+    const int ig = (int)((task / nslab) % nig);
+    const int b = (int)(task / ((long)nslab * nig));
+    const int d0 = slab * 64, i0 = ig * 64;
+    constexpr unsigned OOB = 0x80000000u;
     const float* Wb = W + b * wsb;
-    const float* Xb = X + b * xsb + col;
-    f32x4 acc[8];
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(X) + b * xsb, 0, ((J - 1) * ldx + D) * 4, 0x00020000);
+    const unsigned vx = d0 + 4 * r16 < D ? (unsigned)(q * ldx + d0 + 4 * r16) * 4u : OOB;      // D % 4 == 0
+    f32x4 acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < J; ++j) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(Xb + (long)j * ldx);
+    for (int it = 0; it < 4; ++it)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float w = (i0 + i < I) ? Wb[(long)(i0 + i) * wsi + (long)j * wsj] : 0.f;   // wave-uniform (scalar) load
-            acc[i] += xv * w;
+        for (int jt = 0; jt < 4; ++jt) acc[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nit = min(4, (I - i0 + 15) >> 4);                         // uniform: live row tiles of this group
+    for (int j0 = 0; j0 < J; j0 += 4) {
+        const int j = j0 + q;
+        const f32x4 x4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vx, j0 * ldx * 4, 0));  // rows >= J: 0
+        float a[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = i0 + 16 * it + r16;
+            a[it] = (it < nit && i < I && j < J) ? Wb[(long)i * wsi + (long)j * wsj] : 0.f;
         }
-    }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        if (i0 + i < I) {
-            float* o = out + b * osb + (long)(i0 + i) * ldo + col;
-            f32x4 v = acc[i];
-            if (accumulate) v += *reinterpret_cast<const f32x4*>(o);
-            *reinterpret_cast<f32x4*>(o) = v;
-        }
+        for (int it = 0; it < 4; ++it)
+            if (it < nit)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) acc[it][jt] = mfma16(a[it], x4[jt], acc[it][jt]);
     }
+    // lane holds acc[it][jt][e] = out[i0 + 16it + 4q + e][d0 + 4*r16 + jt]
+    if (d0 + 4 * r16 < D) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i0 + 16 * it + 4 * q + e;
+                if (it < nit && i < I) {
+                    float* o = out + b * osb + (long)i * ldo + d0 + 4 * r16;
+                    f32x4 v = f32x4{acc[it][0][e], acc[it][1][e], acc[it][2][e], acc[it][3][e]};
+                    if (accumulate) v += *reinterpret_cast<const f32x4*>(o);
+                    *reinterpret_cast<f32x4*>(o) = v;
+                }
+            }
+    }
+#endif
 }
 
 // ds[b,t,h] = sum_d g[b,t,d] h[b,h,d]: a small batched "NT" GEMM (per impression [T x D] x [H x D]^T) on the matrix cores.
@@ -119,8 +150,10 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ g
 hipError_t bmm_rows_launch(const float* W, long wsb, long wsi, long wsj, const float* X, long xsb, int ldx,
                            float* out, long osb, int ldo, int B, int I, int J, int D, int accumulate, hipStream_t st) {
     if (B <= 0 || I <= 0) return hipSuccess;
-    hipLaunchKernelGGL(bmm_rows_kernel, dim3((D + 255) / 256, (I + 7) / 8, B), dim3(64), 0, st,
-                       W, wsb, wsi, wsj, X, xsb, ldx, out, osb, ldo, I, J, D, accumulate);
+    const long tasks = (long)B * ((D + 63) / 64) * ((I + 63) / 64);
+    if ((tasks + 3) / 4 > 0x7fffffffL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bmm_rows_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, st,
+                       W, wsb, wsi, wsj, X, xsb, ldx, out, osb, ldo, B, I, J, D, accumulate);
     return hipGetLastError();
 }
 
