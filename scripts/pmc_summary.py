@@ -18,7 +18,7 @@ src = "gpurun_out/final"
 
 stats = glob.glob(f"{src}/stats/*/*_kernel_stats.csv")[0]
 shutil.copy(stats, f"profiles/r1_c3_bench_kernel_stats_{tag}.csv")
-summary = subprocess.run([sys.executable, "scripts/rocprof_summary.py", f"profiles/r1_c3_bench_kernel_stats_{tag}.csv", "7"],
+summary = subprocess.run([sys.executable, "scripts/rocprof_summary.py", f"profiles/r1_c3_bench_kernel_stats_{tag}.csv", "10"],
                          capture_output=True, text=True, check=True).stdout
 open(f"profiles/r1_c3_bench_kernel_stats_{tag}.summary.txt", "w").write(summary)
 print(summary)
