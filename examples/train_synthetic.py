@@ -13,7 +13,7 @@ import tempfile
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from news_recommendation_model_amd import evaluation, synth, trainer          # noqa: E402
+from news_recommendation_model_amd import data_io, evaluation, synth, trainer  # noqa: E402
 from news_recommendation_model_amd.config import Dims, WORKLOADS               # noqa: E402
 
 
@@ -36,9 +36,21 @@ def main():
     torch.manual_seed(args.seed)                                           # train.py:42-43
     model = trainer.build_model(dims, user_num, synth.make_state_dict(dims, seed=args.seed + 1, user_num=user_num))
     opt = trainer.FlatAdam(model, lr=args.lr)                              # train.py:48
-    hosts = [synth.make_batch(dims, B, wl["H"], wl["T"], seed=1000 + i, user_num=user_num) for i in range(args.batches)]
     ckpt_dir = args.ckpt_dir or tempfile.mkdtemp(prefix="nrm_ckpt_")
-    hist = trainer.train_epochs(model, opt, lambda: iter(hosts), args.epochs,
+    # the data takes the reference's route: records in zstd+pickle subvolumes behind a head file (process_data.py:252-291),
+    # read back with load_processed_dataset (:92-145) and batched as DataLoader(shuffle=True) does (train.py:40)
+    records = []
+    for i in range(args.batches):
+        records += data_io.records_from_batch(synth.make_batch(dims, B, wl["H"], wl["T"], seed=1000 + i, user_num=user_num))
+    head = data_io.write_processed_dataset(records, os.path.join(ckpt_dir, "synthetic_train_processed"), subvolume_item_num=4 * B)
+    records, max_user_id = data_io.load_processed_dataset(head)
+    epoch_no = [0]
+
+    def loader():
+        epoch_no[0] += 1
+        return (b for b in data_io.iter_batches(records, B, shuffle=True, seed=args.seed + epoch_no[0]) if len(b["user_id"]) == B)
+    hosts = list(data_io.iter_batches(records, B, shuffle=False))
+    hist = trainer.train_epochs(model, opt, loader, args.epochs,
                                 ckpt_path=os.path.join(ckpt_dir, "ckpt_synthetic_epoch_{epoch}.pth"))
     for rec in hist:
         print("[epoch]:{epoch} [lr]:{lr:.3e} loss_avg={loss_avg:.4f} auc_avg={auc_avg:.4f} impressions={impressions}".format(**rec))
