@@ -362,14 +362,21 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
 #pragma unroll
         for (int jt = 0; jt < DT; ++jt) {
             const int dl = 16 * jt + r16;
-            f32x4 w4[KT];                                                // the column's five LDS reads go out together:
+            // without dW_p (3 waves/SIMD, registers to spare) the column's LDS reads go out together: one latency per
+            // column instead of one per read (serial dh pass 4.36 -> 4.27 ms); with dW_p live that costs registers and
+            // measured 10 % slower on 4x4-tile shapes (D = 768: 22.8 vs 20.5 ms), so there each read feeds its FMAs at once
+            constexpr bool BATCH = !WITH_DW;
+            f32x4 w4[KT];
+            if (BATCH) {
 #pragma unroll
-            for (int it = 0; it < KT; ++it)                              // one latency per column instead of one per read
-                w4[it] = *reinterpret_cast<const f32x4*>(&wpt[dl * LDK + 16 * it + 4 * q]);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int it = 0; it < KT; ++it)
+                    w4[it] = *reinterpret_cast<const f32x4*>(&wpt[dl * LDK + 16 * it + 4 * q]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             float acc = 0.f;
 #pragma unroll
             for (int it = 0; it < KT; ++it) {
+                if (!BATCH) w4[it] = *reinterpret_cast<const f32x4*>(&wpt[dl * LDK + 16 * it + 4 * q]);
                 const f32x4 e4 = E[it][jt];
                 acc = fmaf(w4[it][0], e4[0], fmaf(w4[it][1], e4[1], fmaf(w4[it][2], e4[2], fmaf(w4[it][3], e4[3], acc))));
                 if (WITH_DW) dW[it][jt] += e4 * sr[jt];
