@@ -190,8 +190,6 @@ hipError_t bwd_dz_launch(float* z, const float* ds, const float* w2, float* dw2,
 //
 // KS is kept in the signature for the launch table only (KS == DT: one pass over the tile per group).
 // EXACT: D is a multiple of both tile widths -> no column masks / clamped offsets (fewer VGPRs and VALU).
-template <int N> struct IC { static constexpr int value = N; };
-
 // Column layout of the wide-load contraction kernel: local column c of an 80-wide (or 64-wide) wave tile lives in MFMA
 // tile c&3 at lane-row c>>2 for c < 64 and in tile 4 at lane-row c-64 above; tile_pos is where that column sits in the
 // tile-major order (16*tile + row) the LDS W_p^T image and the accumulators are indexed by.
