@@ -15,6 +15,7 @@
 // MFMA orientation is "transposed": the MFMA row index is k, the MFMA column index is the data row m,
 // so every lane ends up holding 4 consecutive k of one row m -> float4 loads of u/v and float4 stores
 // of z.  All MFMA work is v_mfma_f32_16x16x4_f32 (exact f32).
+#include <cstdlib>
 // timing diagnostics only (scripts/_diag/build_diag.sh): results are WRONG with any of them set
 #ifndef NRM_DIAG_FWD
 #define NRM_DIAG_FWD 0        // bit 0: no accumulator-init loads, bit 1: no K-chunk DMA after the first, bit 2: no z store,
@@ -44,8 +45,8 @@ __global__ void pack_wp_kernel(const float* __restrict__ w, int ldw, int D, int 
     }
 }
 
-template <int NT, int MT, bool SAVE_Z>
-__global__ __launch_bounds__(256, 2) void pwattn_fwd_kernel(const FwdParams p) {
+template <int NT, int MT, bool SAVE_Z, int WPE = 2>
+__global__ __launch_bounds__(256, WPE) void pwattn_fwd_kernel(const FwdParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-descriptor types/builtins exist in the device pass only;
                                          // without the guard the host pass silently drops the kernel stub
     constexpr int BM = 4 * MT * 16;       // data rows per workgroup
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(256, 2) void pwattn_fwd_kernel(const FwdParams p) {
         // accumulators start at u[b,h,k] + v[b,t,k]: the loads land straight in the accumulator
         // registers, so the epilogue needs no u/v traffic.
         const int kc0 = nc * WROWS;
+        const int nt_live = min(NT, (D - kc0 + 15) >> 4);             // uniform: column tiles of this chunk that hold columns < D
         f32x4 acc[NT][MT];
 #pragma unroll
         for (int jt = 0; jt < MT; ++jt) {
@@ -163,6 +165,7 @@ __global__ __launch_bounds__(256, 2) void pwattn_fwd_kernel(const FwdParams p) {
             for (int it = 0; it < NT; ++it) {
                 f32x4 afn = af;
                 if (it + 1 < NT) afn = *reinterpret_cast<const f32x4*>(&buf[((it + 1) * 16 + r16) * 16 + rslot]);
+                if (WPE < 3 || it < nt_live)                          // (13x1 plan) all-padding column tiles of the last N-chunk: no MFMAs
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -219,30 +222,38 @@ __global__ __launch_bounds__(256, 2) void pwattn_fwd_kernel(const FwdParams p) {
 // Tile table: NT 16-column tiles per N-chunk x MT 16-row tiles per wave.  4*NT*MT accumulator registers must
 // stay within 2 waves/SIMD (<= 256 VGPRs), and 2 workgroups x 2 LDS buffers within 160 KB.
 // Up to 25 column tiles (D <= 400) the whole width is ONE N-chunk: no column padding and a single
-// accumulator-init / epilogue per row tile (measured at D=400: 13x3 in two chunks 4.73 ms, 25x1 4.28 ms).
+// accumulator-init / epilogue per row tile (measured at D=400: 13x3 in two chunks 4.73 ms, 25x1 4.28 ms) -- except
+// for 21..26 tiles, see pwattn_fwd_plan.
 static const int kNT[10] = {4, 6, 8, 10, 12, 13, 14, 16, 20, 25};
 static const int kMT[10] = {4, 4, 3, 3, 3, 3, 2, 1, 1, 1};
 
 FwdPlan pwattn_fwd_plan(int D) {
     const int n16 = (D + 15) / 16;
-    const int nch = n16 <= 25 ? 1 : (n16 + 15) / 16;    // wider than 25 tiles: chunks of at most 16 tiles
+    int nch = n16 <= 25 ? 1 : (n16 + 15) / 16;          // wider than 25 tiles: chunks of at most 16 tiles
+    // 21..26 column tiles (320 < D <= 416, incl. D = 400): two N-chunks of 13 tiles with ONE row tile per wave.  That
+    // kernel needs 129 VGPRs and 43 KB of LDS, so three workgroups fit a CU (3 waves/SIMD instead of 2) -- measured at
+    // D = 400: 4.14 ms against 4.29 ms for the single 25-tile chunk, although the rows are streamed twice and the last
+    // chunk carries one all-padding tile (its MFMAs are skipped).  NRM_FWD_13X1=0 restores the one-chunk plan.
+    static const int use13 = [] { const char* e = getenv("NRM_FWD_13X1"); return e && e[0] == '0' ? 0 : 1; }();
+    if (use13 && n16 >= 21 && n16 <= 26) nch = 2;
     const int need = (n16 + nch - 1) / nch;
     int sel = 9;
     for (int i = 0; i < 10; ++i) if (kNT[i] >= need) { sel = i; break; }
     FwdPlan pl;
     pl.NT = kNT[sel]; pl.MT = kMT[sel]; pl.nchunks = nch;
+    if (use13 && pl.NT == 13 && nch == 2 && n16 >= 21) pl.MT = 1;
     pl.rows = nch * pl.NT * 16; pl.kchunks = n16;
     return pl;
 }
 
-template <int NT, int MT>
+template <int NT, int MT, int WPE = 2>
 static hipError_t launch_fwd_t(const FwdParams& p, hipStream_t st) {
     constexpr int BM = 4 * MT * 16;
     const long nblk = (p.M + BM - 1) / BM;
     if (nblk <= 0) return hipSuccess;
     if (nblk > 0x7fffffffL) return hipErrorInvalidValue;
-    if (p.z) hipLaunchKernelGGL((pwattn_fwd_kernel<NT, MT, true>), dim3((unsigned)nblk), dim3(256), 0, st, p);
-    else     hipLaunchKernelGGL((pwattn_fwd_kernel<NT, MT, false>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+    if (p.z) hipLaunchKernelGGL((pwattn_fwd_kernel<NT, MT, true, WPE>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+    else     hipLaunchKernelGGL((pwattn_fwd_kernel<NT, MT, false, WPE>), dim3((unsigned)nblk), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 
@@ -253,7 +264,7 @@ hipError_t pwattn_fwd_launch(const FwdParams& p, const FwdPlan& pl, hipStream_t 
         case 8:  return launch_fwd_t<8, 3>(p, st);
         case 10: return launch_fwd_t<10, 3>(p, st);
         case 12: return launch_fwd_t<12, 3>(p, st);
-        case 13: return launch_fwd_t<13, 3>(p, st);
+        case 13: return pl.MT == 1 ? launch_fwd_t<13, 1, 3>(p, st) : launch_fwd_t<13, 3>(p, st);
         case 14: return launch_fwd_t<14, 2>(p, st);
         case 16: return launch_fwd_t<16, 1>(p, st);
         case 20: return launch_fwd_t<20, 1>(p, st);
