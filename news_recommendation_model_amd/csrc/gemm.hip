@@ -11,6 +11,7 @@
 //             Reduction runs over the ROW index of both operands, so operands stream straight from global
 //             memory into MFMA operand registers (one dword per lane per tile, ping-pong prefetch), the row
 //             range is split over waves and every wave stores one partial slab (transposed: [K][N]).
+#include <cstdlib>
 #include "common.hpp"
 #include "gemm.hpp"
 
@@ -41,8 +42,8 @@ hipError_t pack_rows_launch(const float* src, long rs, long cs, int nrows, int n
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NT, int MT, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNtParams p) {
+template <int NT, int MT, int EPI, int WPE = 2>
+__global__ __launch_bounds__(256, WPE) void gemm_nt_kernel(const GemmNtParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = 4 * MT * 16;
     constexpr int WROWS = NT * 16;
@@ -171,21 +172,21 @@ GemmNtPlan gemm_nt_plan(int N) {
     else {
         // 13x2 (exact for N = 402/416, 3 % padding for 1608) or 8x3, whichever pads less
         const int p13 = (n16 + 12) / 13 * 13, p8 = (n16 + 7) / 8 * 8;
-        if (p13 <= p8) { pl.NT = 13; pl.MT = 2; } else { pl.NT = 8; pl.MT = 3; }
+        if (p13 <= p8) { pl.NT = 13; pl.MT = 1; } else { pl.NT = 8; pl.MT = 3; }
     }
     pl.nchunks = (n16 + pl.NT - 1) / pl.NT;
     pl.rows = pl.nchunks * pl.NT * 16;
     return pl;
 }
 
-template <int NT, int MT>
+template <int NT, int MT, int WPE = 2>
 static hipError_t launch_nt(const GemmNtParams& p, const GemmNtPlan& pl, int epi, hipStream_t st) {
     constexpr int BM = 4 * MT * 16;
     const dim3 grid((p.M + BM - 1) / BM, pl.nchunks), block(256);
     switch (epi) {
-        case EPI_BIAS:  hipLaunchKernelGGL((gemm_nt_kernel<NT, MT, EPI_BIAS>), grid, block, 0, st, p); break;
-        case EPI_GELU:  hipLaunchKernelGGL((gemm_nt_kernel<NT, MT, EPI_GELU>), grid, block, 0, st, p); break;
-        case EPI_DGELU: hipLaunchKernelGGL((gemm_nt_kernel<NT, MT, EPI_DGELU>), grid, block, 0, st, p); break;
+        case EPI_BIAS:  hipLaunchKernelGGL((gemm_nt_kernel<NT, MT, EPI_BIAS, WPE>), grid, block, 0, st, p); break;
+        case EPI_GELU:  hipLaunchKernelGGL((gemm_nt_kernel<NT, MT, EPI_GELU, WPE>), grid, block, 0, st, p); break;
+        case EPI_DGELU: hipLaunchKernelGGL((gemm_nt_kernel<NT, MT, EPI_DGELU, WPE>), grid, block, 0, st, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -195,7 +196,12 @@ hipError_t gemm_nt_launch(const GemmNtParams& p, const GemmNtPlan& pl, int epi, 
     if (p.M <= 0) return hipSuccess;
     if (pl.NT == 4) return launch_nt<4, 4>(p, pl, epi, st);
     if (pl.NT == 8) return launch_nt<8, 3>(p, pl, epi, st);
-    return launch_nt<13, 2>(p, pl, epi, st);
+    // 13 column tiles x ONE row tile per wave: 97 VGPRs and 35 KB of LDS, four workgroups per CU.  Measured on the head's
+    // layers (M = 30 720, 1608 <-> 402): 0.199 ms per launch against 0.211 ms for 13x2 (129 VGPRs, 43 KB, three per CU),
+    // although every W chunk then serves 64 rows instead of 128.  NRM_NT_13X2=1 restores 13x2.
+    static const int use13x2 = [] { const char* e = getenv("NRM_NT_13X2"); return e && e[0] == '1' ? 1 : 0; }();
+    if (use13x2) return launch_nt<13, 2>(p, pl, epi, st);
+    return launch_nt<13, 1, 4>(p, pl, epi, st);
 }
 
 // ---------------------------------------------------------------------------------------------

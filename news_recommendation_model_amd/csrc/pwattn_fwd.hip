@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, WPE) void pwattn_fwd_kernel(const FwdParams p)
 // accumulator-init / epilogue per row tile (measured at D=400: 13x3 in two chunks 4.73 ms, 25x1 4.28 ms) -- except
 // for 21..26 tiles, see pwattn_fwd_plan.
 static const int kNT[10] = {4, 6, 8, 10, 12, 13, 14, 16, 20, 25};
-static const int kMT[10] = {4, 4, 3, 3, 3, 3, 2, 1, 1, 1};
+static const int kMT[10] = {4, 4, 3, 1, 1, 1, 2, 1, 1, 1};     // 10..13 tiles: one row tile per wave, 3 waves/SIMD (3 row tiles spilled)
 
 FwdPlan pwattn_fwd_plan(int D) {
     const int n16 = (D + 15) / 16;
@@ -241,7 +241,6 @@ FwdPlan pwattn_fwd_plan(int D) {
     for (int i = 0; i < 10; ++i) if (kNT[i] >= need) { sel = i; break; }
     FwdPlan pl;
     pl.NT = kNT[sel]; pl.MT = kMT[sel]; pl.nchunks = nch;
-    if (use13 && pl.NT == 13 && nch == 2 && n16 >= 21) pl.MT = 1;
     pl.rows = nch * pl.NT * 16; pl.kchunks = n16;
     return pl;
 }
@@ -262,9 +261,9 @@ hipError_t pwattn_fwd_launch(const FwdParams& p, const FwdPlan& pl, hipStream_t 
         case 4:  return launch_fwd_t<4, 4>(p, st);
         case 6:  return launch_fwd_t<6, 4>(p, st);
         case 8:  return launch_fwd_t<8, 3>(p, st);
-        case 10: return launch_fwd_t<10, 3>(p, st);
-        case 12: return launch_fwd_t<12, 3>(p, st);
-        case 13: return pl.MT == 1 ? launch_fwd_t<13, 1, 3>(p, st) : launch_fwd_t<13, 3>(p, st);
+        case 10: return launch_fwd_t<10, 1, 3>(p, st);
+        case 12: return launch_fwd_t<12, 1, 3>(p, st);
+        case 13: return launch_fwd_t<13, 1, 3>(p, st);
         case 14: return launch_fwd_t<14, 2>(p, st);
         case 16: return launch_fwd_t<16, 1>(p, st);
         case 20: return launch_fwd_t<20, 1>(p, st);
