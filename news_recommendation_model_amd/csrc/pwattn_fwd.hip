@@ -233,7 +233,8 @@ FwdPlan pwattn_fwd_plan(int D) {
     // 21..26 column tiles (320 < D <= 416, incl. D = 400): two N-chunks of 13 tiles with ONE row tile per wave.  That
     // kernel needs 129 VGPRs and 43 KB of LDS, so three workgroups fit a CU (3 waves/SIMD instead of 2) -- measured at
     // D = 400: 4.14 ms against 4.29 ms for the single 25-tile chunk, although the rows are streamed twice and the last
-    // chunk carries one all-padding tile (its MFMAs are skipped).  NRM_FWD_13X1=0 restores the one-chunk plan.
+    // chunk carries one all-padding tile (its MFMAs are skipped); three chunks of 10 tiles at four workgroups per CU:
+    // 4.27 ms.  NRM_FWD_13X1=0 restores the one-chunk plan.
     static const int use13 = [] { const char* e = getenv("NRM_FWD_13X1"); return e && e[0] == '0' ? 0 : 1; }();
     if (use13 && n16 >= 21 && n16 <= 26) nch = 2;
     const int need = (n16 + nch - 1) / nch;
