@@ -208,7 +208,7 @@ hipError_t gemm_nt_launch(const GemmNtParams& p, const GemmNtPlan& pl, int epi, 
 // gemm_tn: every wave owns a (KT*16 i) x (DT*16 j) tile of C[i,j] = sum_r A[r,i] B[r,j] and a row range.
 // slab layout: ws[split][j][ldws] (transposed, float4 along i);  colsum[split][i] = sum_r A[r,i] (tiles j0 == 0).
 template <int KT, int DT>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTnParams p) {
+__global__ __launch_bounds__(256, KT == 4 ? 4 : 3) void gemm_tn_kernel(const GemmTnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
