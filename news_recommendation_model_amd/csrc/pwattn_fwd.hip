@@ -17,6 +17,9 @@
 // of z.  All MFMA work is v_mfma_f32_16x16x4_f32 (exact f32).
 #include <cstdlib>
 // timing diagnostics only (scripts/_diag/build_diag.sh): results are WRONG with any of them set
+#ifndef XCD_REMAP
+#define XCD_REMAP 1
+#endif
 #ifndef NRM_DIAG_FWD
 #define NRM_DIAG_FWD 0        // bit 0: no accumulator-init loads, bit 1: no K-chunk DMA after the first, bit 2: no z store,
 #endif                        // bit 3: no GELU / fc2 dot (plain sum instead)
@@ -60,7 +63,13 @@ __global__ __launch_bounds__(256, WPE) void pwattn_fwd_kernel(const FwdParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, q = lane >> 4;
     const int M = (int)p.M;                       // host guarantees M < 2^31
-    const int m0 = blockIdx.x * BM;
+    // XCD-aware tile order: the hardware deals consecutive block ids round-robin over the 8 XCDs (each with its own L2);
+    // consecutive ROW TILES share their impression's h / u rows and their candidate's t / v row, so give each XCD a
+    // contiguous range of tiles (bijective for any grid size) instead of every eighth one.
+    const int nblk = gridDim.x, lin = blockIdx.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = lin & 7;
+    const int tile_id = XCD_REMAP ? (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3) : lin;
+    const int m0 = tile_id * BM;
     const int T = p.T, H = p.H, D = p.D;
 
     // All global traffic goes through buffer descriptors: 32-bit lane offsets (no 64-bit pointers to keep
