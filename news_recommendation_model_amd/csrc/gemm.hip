@@ -214,9 +214,15 @@ __global__ __launch_bounds__(256, KT == 4 ? 4 : 3) void gemm_tn_kernel(const Gem
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, q = lane >> 4;
-    const int ti = blockIdx.x % p.nti, tj = blockIdx.x / p.nti;
+    // XCD-aware order (as in the backward contractions): the nti*ntj output tiles of one row split read the SAME rows of
+    // A and B; consecutive logical ids go to one XCD, so those rows come from HBM once instead of once per XCD.
+    const int nblk = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = lin & 7;
+    const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+    const int bx = logical % gridDim.x, by = logical / gridDim.x;
+    const int ti = bx % p.nti, tj = bx / p.nti;
     const int i0 = ti * (KT * 16), j0 = tj * (DT * 16);
-    const int split = blockIdx.y * 4 + wave;
+    const int split = by * 4 + wave;
     if (split >= p.nsplit) return;
     const int r_lo = split * p.rps;
     const int r_hi = min(p.R, r_lo + p.rps);
