@@ -164,15 +164,55 @@ def fwd_auc_parity(dev):
 HEAVY = ("nrm_pwattn_fwd", "pwattn_bwd_e_bt", "pwattn_bwd_e_bh", "nrm_pwattn_bwd_dz")   # event-timed inside the timed region
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes of this one (the same
+    command line, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their environment) and leave with the worst exit code.
+    Nothing in this process has touched the GPU yet (device_count() does not initialise it), and nothing is
+    exec'ed over a process that has.  Rank 0 inherits stdout and prints the JSON line."""
+    import socket
+    import subprocess
+    single = os.environ.get("NRM_SINGLE_DEVICE") == "1"
+    ndev = torch.cuda.device_count()
+    if ndev < n and not single:
+        raise SystemExit(f"bench.py --gpus {n}: only {ndev} device(s) visible (a rehearsal of {n} ranks on one GPU needs "
+                         "NRM_SINGLE_DEVICE=1 NRM_DIST_BACKEND=gloo)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NRM_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    worst, alive = 0, list(procs)
+    while alive:
+        for pr in list(alive):
+            rc = pr.poll()
+            if rc is None:
+                continue
+            alive.remove(pr)
+            if rc != 0:
+                worst = worst or rc
+                for other in alive:                 # one rank died: its peers would wait in a collective forever
+                    other.terminate()
+        time.sleep(0.2)
+    raise SystemExit(worst)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     # rehearsal on a one-GPU box: NRM_SINGLE_DEVICE=1 puts every rank on cuda:0 and NRM_DIST_BACKEND=gloo replaces
@@ -328,6 +368,9 @@ def main():
                          "flops_per_launch": flops_per_launch, "mean_launch_ms": round(heavy[dom]["mean_ms"], 4)},
             "kernels": {k: {"launches": v["launches"], "mean_ms": round(v["mean_ms"], 4)} for k, v in kern.items()},
             "grad_allreduce_bytes": opt.nbytes if world > 1 else 0, "replicas_in_sync": replicas_in_sync,
+            "collective": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                            "all_reduce_per_step": 1, "launcher": "self (child processes)" if os.environ.get("NRM_BENCH_CHILD") else "external"}
+                           if world > 1 else None),
         }
         if pcie is not None:
             line["pcie_inclusive"] = pcie

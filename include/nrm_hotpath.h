@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define NRM_ABI_VERSION 1
+#define NRM_ABI_VERSION 2
 #define NRM_OK 0
 #define NRM_EINVAL (-1)   /* bad shape / alignment / null pointer */
 #define NRM_ELAUNCH (-2)  /* HIP launch error */
@@ -103,9 +103,12 @@ int nrm_pool_rowdot(const float* g, const float* h, float* ds, int B, int T, int
 
 /* ---- loss (reference models/user_model.py:37-43): (1-alpha)*BCE(softmax_T(out), y) + alpha*BCE(softmax_T(out +
  * delta[id]), y), mean over B*T, log clamped at -100.  Writes loss_sum[0] += loss, dout [B,T] = dL/dout and
- * ddelta[id[b]] += dL/ddelta (loss_sum and ddelta must be zero-initialised).  T <= 256. */
-int nrm_loss_fwd_bwd(const float* out, const float* label, const long* user_id, const float* delta, float alpha,
-                     int B, int T, float* loss_sum, float* dout, float* ddelta, nrm_stream_t stream);
+ * ddelta[id[b]] += dL/ddelta (loss_sum and ddelta must be zero-initialised).  T <= 256.  delta has n_delta entries;
+ * a negative id counts from the end as in torch indexing, an id still outside [0, n_delta) is clamped and sets
+ * err[0] = 1 (the reference raises IndexError at user_model.py:40; never an out-of-bounds access here). */
+int nrm_loss_fwd_bwd(const float* out, const float* label, const long* user_id, const float* delta, long n_delta,
+                     float alpha, int B, int T, float* loss_sum, float* dout, float* ddelta, int* err,
+                     nrm_stream_t stream);
 
 /* ---- Adam over one flat fp32 buffer (reference train.py:48,73-75): g += wd*p; m,v update; bias correction for
  * `step` (1-based); p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps); optionally zeroes g (optimizer.zero_grad()).

@@ -241,11 +241,11 @@ int nrm_pool_rowdot(const float* g, const float* h, float* ds, int B, int T, int
     return check_hip(nrm::rowdot_launch(g, (long)T * D, D, h, (long)H * D, D, ds, B, T, H, D, (hipStream_t)stream), "pool_rowdot");
 }
 
-int nrm_loss_fwd_bwd(const float* out, const float* label, const long* user_id, const float* delta, float alpha,
-                     int B, int T, float* loss_sum, float* dout, float* ddelta, nrm_stream_t stream) {
-    if (!out || !label || !user_id || !delta || !loss_sum || !dout || !ddelta) return fail(NRM_EINVAL, "nrm_loss_fwd_bwd: null pointer");
-    if (B < 0 || T <= 0 || T > 256) return fail(NRM_EINVAL, "nrm_loss_fwd_bwd: B=%d T=%d (T <= 256)", B, T);
-    return check_hip(nrm::loss_launch(out, label, user_id, delta, alpha, B, T, loss_sum, dout, ddelta, (hipStream_t)stream), "loss");
+int nrm_loss_fwd_bwd(const float* out, const float* label, const long* user_id, const float* delta, long n_delta, float alpha,
+                     int B, int T, float* loss_sum, float* dout, float* ddelta, int* err, nrm_stream_t stream) {
+    if (!out || !label || !user_id || !delta || !loss_sum || !dout || !ddelta || !err) return fail(NRM_EINVAL, "nrm_loss_fwd_bwd: null pointer");
+    if (B < 0 || T <= 0 || T > 256 || n_delta < 1) return fail(NRM_EINVAL, "nrm_loss_fwd_bwd: B=%d T=%d n_delta=%ld (T <= 256, n_delta >= 1)", B, T, n_delta);
+    return check_hip(nrm::loss_launch(out, label, user_id, delta, n_delta, alpha, B, T, loss_sum, dout, ddelta, err, (hipStream_t)stream), "loss");
 }
 
 int nrm_adam_step(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,

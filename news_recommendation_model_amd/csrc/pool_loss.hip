@@ -175,12 +175,20 @@ __device__ __forceinline__ float wave_max64(float v) {
 
 __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out, const float* __restrict__ label,
                                                    const long* __restrict__ uid, const float* __restrict__ delta,
-                                                   float alpha, int B, int T, float* __restrict__ loss_sum,
-                                                   float* __restrict__ dout, float* __restrict__ ddelta) {
+                                                   long n_delta, float alpha, int B, int T, float* __restrict__ loss_sum,
+                                                   float* __restrict__ dout, float* __restrict__ ddelta, int* __restrict__ err) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
-    const float dl = delta[uid[b]];
+    // delta[id] as torch indexes it (models/user_model.py:40): a negative id counts from the end; anything still
+    // outside [0, n_delta) raises IndexError in the reference -- here it is clamped and flagged (never an OOB access)
+    long id = uid[b];
+    if (id < 0) id += n_delta;
+    if (id < 0 || id >= n_delta) {
+        if (lane == 0) *err = 1;
+        id = id < 0 ? 0 : n_delta - 1;
+    }
+    const float dl = delta[id];
     const float inv = 1.0f / ((float)B * (float)T);
     float o[4], y[4];
     float mx = -3.0e38f;
@@ -234,14 +242,15 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out
     }
     if (lane == 0) {
         atomicAdd(loss_sum, total * inv);
-        atomicAdd(ddelta + uid[b], gsum_shift);
+        atomicAdd(ddelta + id, gsum_shift);
     }
 }
 
-hipError_t loss_launch(const float* out, const float* label, const long* uid, const float* delta, float alpha,
-                       int B, int T, float* loss_sum, float* dout, float* ddelta, hipStream_t st) {
+hipError_t loss_launch(const float* out, const float* label, const long* uid, const float* delta, long n_delta, float alpha,
+                       int B, int T, float* loss_sum, float* dout, float* ddelta, int* err, hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(loss_kernel, dim3((B + 3) / 4), dim3(256), 0, st, out, label, uid, delta, alpha, B, T, loss_sum, dout, ddelta);
+    hipLaunchKernelGGL(loss_kernel, dim3((B + 3) / 4), dim3(256), 0, st, out, label, uid, delta, n_delta, alpha, B, T, loss_sum, dout,
+                       ddelta, err);
     return hipGetLastError();
 }
 

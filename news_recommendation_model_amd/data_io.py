@@ -92,55 +92,74 @@ def write_processed_dataset(records, head_path, subvolume_item_num=30000, max_us
     return head_path
 
 
+def _iter_subvolumes(head_file_path, n_sub):
+    """Records of ``<head>.subvolume0 .. <n_sub-1>`` in file order; a missing subvolume is skipped (:110)."""
+    for i in range(n_sub):
+        path = f"{head_file_path}.subvolume{i}"
+        if os.path.isfile(path):
+            yield from import_processed_data(path)
+
+
+class _UserQuota:
+    """Per-user state of the balanced subset: ``pending`` holds the user's records until its block of ``quota`` is
+    full; ``taken`` counts what the user has contributed to the block/extra slots so far."""
+    __slots__ = ("pending", "taken")
+
+    def __init__(self, first):
+        self.pending = [first]
+        self.taken = 1
+
+
+def _balanced_subset(stream, want, quota, extras):
+    """The selection rule of process_data.py:120-143 as a state machine over the record stream.
+
+    * every user first collects a block of ``quota`` records; the block is emitted, whole and in arrival order, at the
+      moment its last record arrives (a block can only be completed by a record that is NOT the user's first -- with
+      quota == 1 no block is ever emitted, as in the reference);
+    * the record after a user's full block is emitted on the spot while the global budget of ``extras`` lasts
+      (one per user); anything later from that user is dropped;
+    * the scan stops as soon as ``want`` records are out; if the stream ends first, the users whose block never
+      filled hand in what they hold, in order of first appearance (this tail is not capped at ``want``)."""
+    out, users = [], {}
+    for rec in stream:
+        uid = rec[1]
+        st = users.get(uid)
+        if st is None:
+            users[uid] = _UserQuota(rec)
+        elif st.taken < quota:
+            st.pending.append(rec)
+            st.taken += 1
+            if st.taken == quota:
+                out.extend(st.pending)
+                st.pending = None
+        elif st.taken == quota and extras > 0:
+            out.append(rec)
+            st.taken += 1
+            extras -= 1
+        if len(out) >= want:
+            return out
+    for st in users.values():
+        if st.taken < quota:
+            out.extend(st.pending)
+    return out
+
+
 def load_processed_dataset(head_file_path, load_data_number=-1, user_min_data_num=2):
-    """process_data.py:92-145, statement for statement (including its quirks): everything when ``load_data_number`` < 0
-    or >= total, otherwise a per-user balanced subset -- every user contributes at most ``max_data_num - 1`` records in
-    blocks (a block is released when it fills), plus one extra record for the first ``max_data_user_num`` users that
-    overflow, and the partial blocks at the end if the quota is still open.  Returns (records, max_user_id)."""
-    subvolume_num, total_data_number, max_user_id, user_num = import_processed_data(head_file_path)
-    if load_data_number < 0:
-        load_data_number = total_data_number
-        max_data_num = total_data_number
-        max_data_user_num = total_data_number
-    else:
-        load_data_number = min(total_data_number, load_data_number)
-        max_data_num = max(int(load_data_number / user_num), user_min_data_num) + 1
-        max_data_user_num = load_data_number - (max_data_num - 1) * user_num
-    processed_data = []
-    user_id_dict = {}
-    for i in range(subvolume_num):
-        subvolume_path = "{}.subvolume{}".format(head_file_path, i)
-        if not os.path.isfile(subvolume_path):
-            continue
-        part = import_processed_data(subvolume_path)
-        if load_data_number == total_data_number:
-            part = part[0:min(load_data_number - len(processed_data), len(part))]
-            processed_data = processed_data + part
-        else:
-            for data in part:
-                user_id = data[1]
-                if user_id in user_id_dict:
-                    held = user_id_dict[user_id]
-                    if len(held) == max_data_num - 1 and max_data_user_num > 0:
-                        processed_data.append(data)
-                        held.append(0)
-                        max_data_user_num -= 1
-                    elif len(held) <= max_data_num - 2:
-                        held.append(data)
-                        if len(held) == max_data_num - 1:
-                            processed_data += held
-                            user_id_dict[user_id] = [0] * (max_data_num - 1)       # placeholders: block already released
-                else:
-                    user_id_dict[user_id] = [data]
-                if len(processed_data) >= load_data_number:
-                    break
-        if len(processed_data) >= load_data_number:
-            break
-    if len(processed_data) < load_data_number:
-        for data_list in user_id_dict.values():
-            if len(data_list) < max_data_num - 1:
-                processed_data += data_list
-    return processed_data, max_user_id
+    """Behaviour of process_data.py:92-145.  ``load_data_number`` < 0 or >= the total: the first ``total`` records of
+    the subvolumes, in file order.  Otherwise a per-user balanced subset (``_balanced_subset``): block size
+    ``max(load_data_number // user_num, user_min_data_num)``, and ``load_data_number - block * user_num`` users may add
+    one record beyond their block.  Returns (records, max_user_id).  PARITY UNPINNED (module docstring)."""
+    n_sub, total, max_user_id, n_users = import_processed_data(head_file_path)
+    stream = _iter_subvolumes(head_file_path, n_sub)
+    if load_data_number < 0 or load_data_number >= total:
+        records = []
+        for rec in stream:
+            if len(records) >= total:
+                break
+            records.append(rec)
+        return records, max_user_id
+    quota = max(int(load_data_number / n_users), user_min_data_num)
+    return _balanced_subset(stream, load_data_number, quota, load_data_number - quota * n_users), max_user_id
 
 
 # ------------------------------------------------------------------------------------------------ batching

@@ -11,7 +11,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NRM_HOTPATH_LIB") or os.path.join(_HERE, "libnrm_hotpath.so")   # override: diagnostic builds (scripts/_diag)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_fp = ctypes.c_void_p      # device pointers travel as integers
 _c_i, _c_l = ctypes.c_int, ctypes.c_long
@@ -36,7 +36,7 @@ SIGNATURES = {
     "nrm_bn_backward": (_c_i, [_c_fp] * 8 + [_c_i] * 4 + [_c_fp]),
     "nrm_pool_bmm": (_c_i, [_c_fp, _c_l, _c_l, _c_l, _c_fp, _c_fp] + [_c_i] * 5 + [_c_fp]),
     "nrm_pool_rowdot": (_c_i, [_c_fp] * 3 + [_c_i] * 4 + [_c_fp]),
-    "nrm_loss_fwd_bwd": (_c_i, [_c_fp] * 4 + [ctypes.c_float, _c_i, _c_i] + [_c_fp] * 4),
+    "nrm_loss_fwd_bwd": (_c_i, [_c_fp] * 4 + [_c_l, ctypes.c_float, _c_i, _c_i] + [_c_fp] * 5),
     "nrm_adam_step": (_c_i, [_c_fp] * 4 + [_c_l] + [ctypes.c_float] * 5 + [_c_i, _c_i, _c_fp]),
     "nrm_adam_step_dev": (_c_i, [_c_fp] * 4 + [_c_l] + [ctypes.c_float] * 5 + [_c_fp, _c_i, _c_fp]),
     "nrm_row_auc": (_c_i, [_c_fp] * 3 + [_c_i, _c_i] + [_c_fp] * 3),

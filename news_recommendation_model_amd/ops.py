@@ -55,7 +55,7 @@ class _PointwiseAttentionScores(torch.autograd.Function):
         a_t = w_t + w_d
         u, _ = _gemm_nt(h.reshape(B * H, D), a_h.contiguous(), D, 1, D, D, b1, 0)      # [B*H, D]
         v, _ = _gemm_nt(t.reshape(B * T, D), a_t.contiguous(), D, 1, D, D, None, 0)    # [B*T, D]
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = any(ctx.needs_input_grad) and torch.is_grad_enabled()      # no [B,T,H,D] buffer under no_grad / eval
         st = native.stream_ptr()
         packed = torch.empty(native.load().nrm_pwattn_packed_floats(D), dtype=torch.float32, device=t.device)
         native.call("nrm_pwattn_pack_wp", native.ptr(w1), 4 * D, D, native.ptr(packed), st)
@@ -67,10 +67,18 @@ class _PointwiseAttentionScores(torch.autograd.Function):
         if need_grad:
             ctx.save_for_backward(t, h, w1, w2v, z)
             ctx.w2_shape = tuple(w2.shape)
+            ctx.z_consumed = False
         return s
 
     @staticmethod
     def backward(ctx, ds):
+        if ctx.z_consumed:
+            # the saved pre-activation is overwritten in place by dz below (2.46 GB at C3: no second copy), so the
+            # graph can be walked once; the reference's autograd would allow retain_graph=True here
+            raise RuntimeError("pointwise attention: backward through this graph a second time is not supported "
+                               "(the saved pre-activation buffer was consumed by the first backward); "
+                               "re-run the forward instead of retain_graph=True")
+        ctx.z_consumed = True
         t, h, w1, w2v, z = ctx.saved_tensors
         B, T, D = t.shape
         H = h.shape[1]
@@ -390,8 +398,9 @@ class _SoftmaxBceLoss(torch.autograd.Function):
         loss = torch.zeros(1, dtype=torch.float32, device=out.device)
         dout = torch.empty(B, T, dtype=torch.float32, device=out.device)
         ddelta = torch.zeros_like(d)
-        native.call("nrm_loss_fwd_bwd", native.ptr(o), native.ptr(y), native.ptr(uid), native.ptr(d), float(alpha),
-                    B, T, native.ptr(loss), native.ptr(dout), native.ptr(ddelta), native.stream_ptr())
+        native.call("nrm_loss_fwd_bwd", native.ptr(o), native.ptr(y), native.ptr(uid), native.ptr(d), d.numel(), float(alpha),
+                    B, T, native.ptr(loss), native.ptr(dout), native.ptr(ddelta), native.ptr(index_error_flag(out.device)),
+                    native.stream_ptr())
         ctx.save_for_backward(dout, ddelta)
         return loss.reshape(())
 

@@ -45,6 +45,13 @@ CASES = {
     "c3_large":    dict(B=2, H=50, T=30, emb=400, cat=100, mode="train", full=False),
     "c5_long":     dict(B=1, H=128, T=64, emb=768, cat=100, mode="train", full=False),
 }
+# K-step trajectories of the reference's own training loop (train.py:66-75 repeated, torch.optim.Adam stepping every
+# time): what pins BatchNorm running statistics, Adam moments and the -100 clamp regime of the loss beyond step 1.
+# "fresh_batches": a new seeded batch per step (seed = step), else the same batch every step (as bench.py does).
+TRAJ_CASES = {
+    "traj_tiny": dict(B=4, H=8, T=5, emb=64, cat=50, steps=8, fresh_batches=True),
+    "traj_c3":   dict(B=8, H=50, T=30, emb=400, cat=100, steps=8, fresh_batches=False),
+}
 SAMPLE = 1024
 ZERO_GRAD_KEYS = ("delta", "out_mlp.fc2.bias")
 
@@ -169,6 +176,68 @@ def run_case(name, case, outdir):
     return diffs
 
 
+def traj_batches(case, dims):
+    user_num = 10 * case["B"]
+    seeds = range(case["steps"]) if case["fresh_batches"] else [0] * case["steps"]
+    return user_num, [synth.make_batch(dims, case["B"], case["H"], case["T"], seed=s, user_num=user_num) for s in seeds]
+
+
+def run_trajectory(name, case, outdir):
+    """K steps of the REFERENCE model + torch.optim.Adam(lr 1e-3, weight_decay 1e-5) (train.py:48,66-75); the oracle
+    takes the same K steps beside it.  Stored per step: loss, logits (sample), max |logit|, BatchNorm running
+    statistics; at the end: every parameter and both Adam moments (samples)."""
+    dims = Dims.for_emb(case["emb"], category_label_num=case["cat"])
+    user_num, batches = traj_batches(case, dims)
+    sd = synth.make_state_dict(dims, seed=1, user_num=user_num, perturb=False)        # PyTorch-default BN / delta, as train.py:46
+    UserModel = build_reference(dims)
+    model = UserModel(user_num)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    p = orc.to_torch_params(sd)
+    ost = {"step": 0, "m": {}, "v": {}}
+    K = case["steps"]
+    fx = {"loss": np.zeros(K, np.float64), "maxlogit": np.zeros(K, np.float64)}
+    rs, rms, rvs = [], [], []
+    diffs = {"loss_rel": 0.0, "r_rel": 0.0, "bn_rel": 0.0}
+    for step, batch in enumerate(batches):
+        tb = {k: torch.from_numpy(v) for k, v in batch.items() if isinstance(v, np.ndarray) and v.ndim > 0}
+        r = model(tb["x_history"], tb["x_target"], tb["x_global"])
+        loss = model.loss(tb["user_id"], r, tb["label"])
+        loss.backward()
+        opt.step(); opt.zero_grad()
+        loss_o, r_o, _ = orc.train_step(p, ost, tb)
+        fx["loss"][step] = float(loss.detach())
+        fx["maxlogit"][step] = float(r.detach().abs().max())
+        rr = r.detach().numpy().reshape(-1)
+        rs.append(rr[sample_idx(rr.size)])
+        rms.append(model.bn.running_mean.numpy().copy()[sample_idx(model.bn.running_mean.numel())])
+        rvs.append(model.bn.running_var.numpy().copy()[sample_idx(model.bn.running_var.numel())])
+        diffs["loss_rel"] = max(diffs["loss_rel"], abs(float(loss.detach()) - float(loss_o)) / abs(float(loss.detach())))
+        diffs["r_rel"] = max(diffs["r_rel"], float((r.detach() - r_o).abs().max() / r.detach().abs().max()))
+        diffs["bn_rel"] = max(diffs["bn_rel"], float((model.bn.running_var - p["bn.running_var"]).abs().max()
+                                                     / model.bn.running_var.abs().max()))
+    fx["r"], fx["running_mean"], fx["running_var"] = np.stack(rs), np.stack(rms), np.stack(rvs)
+    worst = 0.0
+    for k, v in model.named_parameters():
+        a = v.detach().numpy().reshape(-1)
+        idx = sample_idx(a.size)
+        fx["after/" + k] = a[idx]
+        st = opt.state[v]
+        fx["m/" + k] = st["exp_avg"].numpy().reshape(-1)[idx]
+        fx["v/" + k] = st["exp_avg_sq"].numpy().reshape(-1)[idx]
+        before = np.asarray(sd[k]).reshape(-1)[idx].astype(np.float64)
+        move = np.linalg.norm(a[idx].astype(np.float64) - before)
+        if move > 0 and k not in ZERO_GRAD_KEYS:       # those two follow the sign of rounding noise (gradient == 0 in exact arithmetic)
+            worst = max(worst, float(np.linalg.norm(a[idx].astype(np.float64) - p[k].detach().numpy().reshape(-1)[idx]) / move))
+    diffs["param_move_rel"] = worst          # |p_ref - p_oracle| / |p_ref - p_start|, worst tensor outside ZERO_GRAD_KEYS
+    fx["checksum_inputs"] = np.float64(sum(checksum([b["x_history"], b["x_target"], b["x_global"], b["label"], b["user_id"]])
+                                           for b in batches))
+    fx["checksum_weights"] = np.float64(checksum(sd.values()))
+    np.savez_compressed(os.path.join(outdir, name + ".npz"), **fx)
+    return diffs
+
+
 def attention_2d_case(outdir):
     """PointwiseAttentionExpanded with a 2-D target [B,D] (models/attention_model.py:64-65) and the
     stand-alone MLP, at D=64."""
@@ -248,6 +317,20 @@ def degenerate_case(outdir):
 
 
 def main():
+    if "--only-traj" in sys.argv:                                   # add / refresh the trajectory fixtures only
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        outdir = os.path.join(ROOT, "tests", "golden")
+        with open(os.path.join(outdir, "MANIFEST.json")) as f:
+            manifest = json.load(f)
+        manifest["trajectories"] = {}
+        for name, case in TRAJ_CASES.items():
+            diffs = run_trajectory(name, case, outdir)
+            manifest["trajectories"][name] = {"case": case, "oracle_vs_reference": diffs}
+            print(name, diffs, flush=True)
+        with open(os.path.join(outdir, "MANIFEST.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
     if "--only-degenerate" in sys.argv:                             # add / refresh that one entry, leave the rest alone
         outdir = os.path.join(ROOT, "tests", "golden")
         with open(os.path.join(outdir, "MANIFEST.json")) as f:
@@ -271,6 +354,11 @@ def main():
     print("attention_2d", manifest["cases"]["attention_2d"]["oracle_vs_reference"])
     manifest["degenerate"] = degenerate_case(outdir)
     print("degenerate", manifest["degenerate"])
+    manifest["trajectories"] = {}
+    for name, case in TRAJ_CASES.items():
+        diffs = run_trajectory(name, case, outdir)
+        manifest["trajectories"][name] = {"case": case, "oracle_vs_reference": diffs}
+        print(name, diffs, flush=True)
     with open(os.path.join(outdir, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
 

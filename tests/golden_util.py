@@ -59,3 +59,101 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+# ----------------------------------------------------------------------------------------- Adam update / trajectories
+def assert_first_adam_update(key, before, got_after, fx, full, lr=1e-3, weight_decay=1e-5):
+    """Parameters after ONE Adam(lr, weight_decay) step against the reference fixture, as a check of the UPDATE
+    (p_after - p_before), not of the value: the first step moves every weight by -lr * g'/(|g'| + eps) with
+    g' = g + weight_decay * p, i.e. by ~lr in the direction of -sign(g'), so a value tolerance of a few lr would
+    accept an optimizer that does nothing.  Entries whose |g'| is within rounding noise of zero (their sign is not
+    determined) are only bounded by lr; everything else -- including rows with an exactly-zero gradient, which move
+    by weight decay alone -- must agree with the reference's update to 1e-5 absolute (1 % of lr)."""
+    b = pick(before, full).astype(np.float64)
+    ref_after = np.asarray(fx["after/" + key], dtype=np.float64)
+    got = pick(got_after, full).astype(np.float64)
+    d_ref, d_got = ref_after - b, got - b
+    assert np.abs(d_got).max() <= lr * (1 + 1e-3) + 1e-9, key                 # Adam's first step never exceeds lr
+    if "grad/" + key not in fx.files:                                        # buffers: not optimizer state
+        return 0.0
+    g = np.asarray(fx["grad/" + key], dtype=np.float64)
+    gp = g + weight_decay * b
+    thresh = max(1e-6, 1e-4 * np.abs(g).max())
+    sure = (np.abs(gp) > thresh) | (g == 0.0)
+    if key in ZERO_GRAD_KEYS or not sure.any():
+        return 0.0
+    assert np.abs(d_got - d_ref)[sure].max() <= 1e-5, (key, float(np.abs(d_got - d_ref)[sure].max()))
+    moved = sure & (np.abs(gp) > 1e-6)
+    if moved.any():
+        assert np.abs(d_got)[moved].min() >= 0.9 * lr, key                    # it really stepped
+    return float(sure.mean())
+
+
+TRAJ_CASES = list(MANIFEST.get("trajectories", {}))
+
+
+def load_trajectory(name):
+    """-> (case, dims, user_num, batches (list of numpy dicts, one per step), state_dict, fixture)"""
+    case = MANIFEST["trajectories"][name]["case"]
+    dims = Dims.for_emb(case["emb"], category_label_num=case["cat"])
+    user_num = 10 * case["B"]
+    seeds = range(case["steps"]) if case["fresh_batches"] else [0] * case["steps"]
+    batches = [synth.make_batch(dims, case["B"], case["H"], case["T"], seed=s, user_num=user_num) for s in seeds]
+    sd = synth.make_state_dict(dims, seed=1, user_num=user_num, perturb=False)
+    fx = np.load(os.path.join(GOLDEN, name + ".npz"))
+    got = sum(checksum([b["x_history"], b["x_target"], b["x_global"], b["label"], b["user_id"]]) for b in batches)
+    assert abs(got - float(fx["checksum_inputs"])) < 1e-6 * max(1.0, abs(got))
+    assert abs(checksum(sd.values()) - float(fx["checksum_weights"])) < 1e-6
+    return case, dims, user_num, batches, sd, fx
+
+
+def check_trajectory(fx, sd, losses, rs, running_means, running_vars, params, exp_avg, exp_avg_sq,
+                     loss_tol=1e-3, logit_tol=1e-3, bn_tol=1e-3, move_tol=1e-3, moment_tol=1e-2, logit_cap=1e3):
+    """K steps of the train.py:66-75 loop against the REFERENCE's own trajectory (oracle/make_golden.py
+    run_trajectory).  Per step: loss and logits (relative, while max|logit| < logit_cap -- beyond it the loss sits on
+    its -100 clamp), BatchNorm running statistics (norm-wise relative).  At the end: every parameter's total move
+    |p_K - p_ref_K| / |p_ref_K - p_0| and both Adam moments, norm-wise; the two zero-gradient keys are skipped (their
+    updates follow the sign of rounding noise in the reference too).  Returns the worst figures for the log."""
+    worst = {"loss": 0.0, "logit": 0.0, "bn": 0.0, "move": 0.0, "m": 0.0, "v": 0.0}
+    K = len(fx["loss"])
+    assert len(losses) == K
+    for s in range(K):
+        if fx["maxlogit"][s] < logit_cap:
+            e = abs(losses[s] - fx["loss"][s]) / abs(fx["loss"][s])
+            worst["loss"] = max(worst["loss"], e)
+            assert e <= loss_tol, ("loss", s, losses[s], float(fx["loss"][s]))
+            r = np.asarray(rs[s]).reshape(-1)
+            e = rel_err(r[sample_idx(r.size)], fx["r"][s])
+            worst["logit"] = max(worst["logit"], e)
+            assert e <= logit_tol, ("logits", s, e)
+        for got, key in ((running_means[s], "running_mean"), (running_vars[s], "running_var")):
+            g = np.asarray(got).reshape(-1)
+            e = rel_err(g[sample_idx(g.size)], fx[key][s])
+            worst["bn"] = max(worst["bn"], e)
+            assert e <= bn_tol, (key, s, e)
+    for k in params:
+        if k in ZERO_GRAD_KEYS or "after/" + k not in fx.files:
+            continue
+        a = np.asarray(params[k]).reshape(-1)
+        idx = sample_idx(a.size)
+        ref = fx["after/" + k].astype(np.float64)
+        start = np.asarray(sd[k]).reshape(-1)[idx].astype(np.float64)
+        move = np.linalg.norm(ref - start)
+        e = float(np.linalg.norm(a[idx].astype(np.float64) - ref) / move)
+        # allowance for ONE entry whose near-zero gradient took the other sign for one step (Adam then moves it by
+        # 2 lr the other way; the tensor as a whole moved ~ sqrt(n) K lr): only matters for the handful of tiny
+        # tensors (8-entry instant-interest bias, 1-entry fc2 biases), whose reference trajectory itself changes
+        # between two runs of make_golden.py by this much (multi-threaded reductions)
+        tol_k = max(move_tol, 2.5 / (np.sqrt(a.size) * K))
+        if tol_k == move_tol:
+            worst["move"] = max(worst["move"], e)
+        assert e <= tol_k, ("parameter move", k, e, tol_k)
+        for got, pre, name in ((exp_avg, "m/", "m"), (exp_avg_sq, "v/", "v")):
+            if got is None:
+                continue
+            gm = np.asarray(got[k]).reshape(-1)[idx].astype(np.float64)
+            rm = fx[pre + k].astype(np.float64)
+            e = float(np.linalg.norm(gm - rm) / (np.linalg.norm(rm) + 1e-30))
+            worst[name] = max(worst[name], e)
+            assert e <= moment_tol, ("adam " + name, k, e)
+    return worst

@@ -97,3 +97,60 @@ def test_collate_and_batches_feed_the_model_fields():
         assert b["x_target"].shape[1:] == batch["x_target"].shape[1:]
         seen += list(b["impression_id"])
     assert sorted(seen) == list(range(6)) and seen != list(range(6))
+
+
+def _brute_force_subset(users, want, n_users, user_min):
+    """Event-based statement of the selection rule (no per-record state machine): for a prefix of c records, user u with
+    arrivals a_1 < a_2 < ... has its block of q records emitted at time a_q (if q >= 2 arrivals... a block is completed
+    only by a non-first record, so q == 1 never emits) and its (q+1)-th arrival emitted at that time if fewer than
+    `extras` extras were granted before it.  The cut is the shortest prefix that emits >= want records; if the whole
+    stream emits fewer, users with < q arrivals append theirs in order of first appearance."""
+    q = max(int(want / n_users), user_min)
+    extras = want - q * n_users
+
+    def emitted(c):
+        arrivals = {}
+        for i in range(c):
+            arrivals.setdefault(users[i], []).append(i)
+        events = []                                                    # (time, records)
+        for u, a in arrivals.items():
+            if q >= 2 and len(a) >= q:
+                events.append((a[q - 1], a[:q]))
+        # extras are granted in time order of the (q+1)-th arrivals
+        cand = sorted(a[q] for a in arrivals.values() if len(a) > q)
+        for t in cand[:max(extras, 0)]:
+            events.append((t, [t]))
+        out = []
+        for _t, recs in sorted(events):
+            out += recs
+        return out, arrivals
+    n = len(users)
+    for c in range(1, n + 1):
+        out, arrivals = emitted(c)
+        if len(out) >= want:
+            return out
+    out, arrivals = emitted(n)
+    for u, a in arrivals.items():                                      # dicts keep first-appearance order
+        if len(a) < q:
+            out += a
+    return out
+
+
+def test_balanced_subset_randomized_against_brute_force(tmp_path):
+    rng = np.random.default_rng(2024)
+    for trial in range(60):
+        n = int(rng.integers(1, 40))
+        pool = int(rng.integers(1, 9))
+        users = [int(u) for u in rng.integers(0, pool, n)]
+        n_users = len(set(users)) if rng.random() < 0.7 else int(rng.integers(1, pool + 3))     # the head's user_num may be stale
+        want = int(rng.integers(1, n + 1))
+        user_min = int(rng.integers(1, 4))
+        recs = _records(users, P=2, H=1, T=2)
+        head = str(tmp_path / f"d{trial}")
+        data_io.write_processed_dataset(recs, head, subvolume_item_num=int(rng.integers(1, 12)), user_num=n_users)
+        got, _ = data_io.load_processed_dataset(head, load_data_number=want, user_min_data_num=user_min)
+        if want >= n:
+            expect = list(range(n))
+        else:
+            expect = _brute_force_subset(users, want, n_users, user_min)
+        assert [r[0] - 1000 for r in got] == expect, (trial, users, want, n_users, user_min)

@@ -1,0 +1,77 @@
+"""GPU: the data-parallel step of BASELINE config 4 on the HIP path (insertion point of the collective:
+reference train.py:73-74).  Two ranks, both on cuda:0 of the 1-GPU test box, gloo process group (RCCL needs one
+device per rank; the 8-GPU run of bench.py uses backend nccl over the same FlatAdam.all_reduce_grads).  The assertions
+live in tests/dp_worker.py; here the two rank processes are started as children (nothing is exec'ed over this
+process, which has initialised the GPU) and their verdicts collected."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run_ranks(cmd_for_rank, world, tmp_path, timeout=420, extra_env=None):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), NRM_DIST_BACKEND="gloo", NRM_SINGLE_DEVICE="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen(cmd_for_rank(r), env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode(errors="replace"))
+    return procs, outs
+
+
+def test_two_rank_hip_train_step_one_collective_identical_replicas(lib, tmp_path):
+    world = 2
+    paths = [str(tmp_path / f"rank{r}.json") for r in range(world)]
+    procs, outs = _run_ranks(lambda r: [sys.executable, os.path.join(HERE, "dp_worker.py"), paths[r]], world, tmp_path)
+    for r in range(world):
+        assert os.path.exists(paths[r]), outs[r][-2000:]
+        res = json.load(open(paths[r]))
+        assert res["ok"], res.get("error", outs[r][-2000:])
+        assert res["bn_stats_differ"]                       # per-replica BatchNorm, as DESIGN.md §6 states
+        assert res["grad_max_rel_err_vs_oracle"] < 1e-2
+    assert all(pr.returncode == 0 for pr in procs)
+
+
+def test_bench_self_launches_two_ranks(lib, tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it: bench starts its own rank processes and rank 0 prints the
+    one JSON line (the shape of command the driver runs for N > 1; here both ranks share cuda:0 over gloo)."""
+    env = dict(os.environ, NRM_SINGLE_DEVICE="1", NRM_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                         "--workload", "ref-default", "--batch", "16", "--no-cpu-baseline"],
+                        env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+    assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in pr.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, pr.stdout.decode()[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 32 and line["scaling"] == "weak"
+    assert line["replicas_in_sync"] is True
+    assert line["grad_allreduce_bytes"] > 0
+    assert line["collective"]["world_size"] == 2 and line["collective"]["all_reduce_per_step"] == 1

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import MODEL_CASES, ZERO_GRAD_KEYS, load_case, pick, rel_err
+from golden_util import (MODEL_CASES, TRAJ_CASES, ZERO_GRAD_KEYS, assert_first_adam_update, check_trajectory, load_case,
+                         load_trajectory, pick, rel_err)
 from oracle import user_model_oracle as orc
 
 
@@ -37,12 +38,32 @@ def test_oracle_matches_fixture(name):
             assert np.abs(got).max() < 1e-6 * max(1.0, gscale)
         else:
             assert np.abs(got - ref).max() <= 1e-2 * np.abs(ref).max() + 1e-9, k
-    # Adam: wherever |g| >> eps the first step moves a weight by ~lr*sign(g); compare absolutely
-    for k in p:
-        ref = fx["after/" + k]
-        got = pick(p[k].detach().numpy(), full)
-        assert np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() < 2.5e-3, k
+    # Adam: the UPDATE (after - before) against the reference's, entry by entry (golden_util.assert_first_adam_update)
+    checked = [assert_first_adam_update(k, sd[k], p[k].detach().numpy(), fx, full) for k in p if k not in orc.BUFFER_KEYS]
+    assert max(checked) > 0.5                      # most entries of the dense tensors have a determined sign
+    for k in ("bn.running_mean", "bn.running_var"):
+        assert rel_err(pick(p[k].numpy(), full), fx["after/" + k]) < 1e-5, k
     np.testing.assert_allclose(orc.batch_auc(batch["label"], fx["r"]), fx["auc"], atol=1e-12)
+
+
+@pytest.mark.parametrize("name", TRAJ_CASES)
+def test_oracle_follows_the_reference_trajectory(name):
+    """8 steps of the reference's loop (same batch every step at C3 dimensions: the logits grow to ~240 and the loss
+    reaches its guarded/clamped regime; fresh batches on the tiny model): loss, logits, BatchNorm running statistics
+    per step, parameters and Adam moments at the end."""
+    case, dims, user_num, batches, sd, fx = load_trajectory(name)
+    p = orc.to_torch_params(sd)
+    st = {"step": 0, "m": {}, "v": {}}
+    losses, rs, rms, rvs = [], [], [], []
+    for b in batches:
+        tb = {k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray) and v.ndim > 0}
+        loss, r, _ = orc.train_step(p, st, tb)
+        losses.append(float(loss)); rs.append(r.numpy().copy())
+        rms.append(p["bn.running_mean"].numpy().copy()); rvs.append(p["bn.running_var"].numpy().copy())
+    params = {k: v.detach().numpy() for k, v in p.items() if k not in orc.BUFFER_KEYS}
+    worst = check_trajectory(fx, sd, losses, rs, rms, rvs, params, {k: v.numpy() for k, v in st["m"].items()},
+                             {k: v.numpy() for k, v in st["v"].items()}, move_tol=5e-3)
+    print(name, worst)
 
 
 def test_oracle_attention_2d_target():
