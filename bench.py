@@ -35,6 +35,7 @@ import torch
 import torch.distributed as dist
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PMC_TRAFFIC_FILES = {"C3-large": "r2_c3_pmc_traffic.json", "C5-long": "r2_c5_pmc_traffic.json", "C2-small": "r2_c2_pmc_traffic.json"}
 
 
 def parse():
@@ -47,6 +48,10 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="capture the step in a HIP graph and time graph replays (per-kernel event timing then "
                          "comes from 3 extra eager steps outside the timed region)")
+    ap.add_argument("--eager", action="store_true",
+                    help="never replay a graph.  Default (neither flag): eager when a step takes >= 10 ms (C3, C5: the ~600 "
+                         "launches of a step hide behind the kernels and the heavy kernels can be event-timed inside the timed "
+                         "region), hipGraph replay when it is shorter (the step is then bound by host launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not bracket every launch with HIP events inside the timed region (the per-kernel durations "
@@ -251,6 +256,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if not args.graph and not args.eager and world == 1:
+        # launch mode by measurement: two eager steps (after two warm-up steps), mean wall time per step
+        for _ in range(2):
+            trainer.train_step(model, opt, tb, reducer)
+        sync()
+        t_probe = time.perf_counter()
+        for _ in range(2):
+            trainer.train_step(model, opt, tb, reducer)
+        sync()
+        if (time.perf_counter() - t_probe) / 2 < 10e-3:
+            args.graph = True
     if args.graph or args.no_kernel_timing:
         # per-kernel durations cannot be event-timed inside a graph: take them from 3 eager steps first
         for _ in range(2):
@@ -341,15 +357,23 @@ def main():
     flops_per_launch = 2.0 * B * T * H * D * D            # both attentions have width D in BASELINE shapes
     achieved = flops_per_launch / (heavy[dom]["mean_ms"] * 1e-3) / 1e12
 
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure comes
-    # from the committed rocprofv3 --pmc passes of this same command (profiles/r1_c3_pmc_traffic.json, C3 only)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r1_c3_pmc_traffic.json")
-    if args.workload == "C3-large" and not args.batch and os.path.exists(tpath):
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure comes from
+    # the committed rocprofv3 --pmc passes of this same command (profiles/<round>_<workload>_pmc_traffic.json, written by
+    # scripts/pmc_summary.py, which stamps the digest of the kernel sources it measured).  A profile of other sources
+    # is stale: traffic is then null and the note says so.
+    traffic, traffic_note = None, "no committed PMC profile for this workload"
+    from news_recommendation_model_amd import build as _build
+    tpath = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILES.get(args.workload, ""))
+    if not args.batch and os.path.isfile(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dom, {}).get("corrected_bytes")
-        except Exception:
-            traffic = None
+            prof = json.load(open(tpath))
+            if prof.get("kernel_sources_sha256") != _build.sources_digest():
+                traffic_note = f"stale: {os.path.basename(tpath)} was measured on other kernel sources (commit {prof.get('git_head', '?')})"
+            else:
+                traffic = prof.get(dom, {}).get("corrected_bytes")
+                traffic_note = f"{os.path.basename(tpath)} (rocprofv3 --pmc, commit {prof.get('git_head', '?')}, same kernel sources)"
+        except Exception as e:
+            traffic_note = "unreadable profile: " + repr(e)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -364,7 +388,7 @@ def main():
                        "step": "fwd+loss+bwd+allreduce+Adam(wd=1e-5)" if world > 1 else "fwd+loss+bwd+Adam(wd=1e-5)"},
             "loss": round(float(loss), 6),
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_note,
                          "flops_per_launch": flops_per_launch, "mean_launch_ms": round(heavy[dom]["mean_ms"], 4)},
             "kernels": {k: {"launches": v["launches"], "mean_ms": round(v["mean_ms"], 4)} for k, v in kern.items()},
             "grad_allreduce_bytes": opt.nbytes if world > 1 else 0, "replicas_in_sync": replicas_in_sync,

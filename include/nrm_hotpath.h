@@ -68,24 +68,42 @@ int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, con
 #define NRM_EPI_BIAS 0   /* y = x W^T + bias                                                              */
 #define NRM_EPI_GELU 1   /* z = x W^T + bias (saved for backward), y = gelu(z)                            */
 #define NRM_EPI_DGELU 2  /* y = (x W^T) * gelu'(z)      (z = pre-activation saved by NRM_EPI_GELU)        */
+#define NRM_EPI_MUL 3    /* z = x W^T + bias (kept for backward), y = z * m: the gate of user_model.py:33 */
 long nrm_gemm_packed_floats(int nrows, int ncols);
 /* packs the logical [nrows x ncols] matrix src[r*row_stride + c*col_stride]; rows become output columns of
  * nrm_gemm_nt, columns its reduction index.  Linear.forward: (W[N,K], K, 1, N, K); dX = dY W: (W, 1, K, K, N) */
 int nrm_gemm_pack(const float* src, long row_stride, long col_stride, int nrows, int ncols, float* packed,
                   nrm_stream_t stream);
-/* y[M, N] (ld ldy) = epilogue( x[M, K] (ld ldx) * packed^T ), bias [N] or NULL */
+/* y[M, N] (ld ldy) = epilogue( x[M, K] (ld ldx) * packed^T ), bias [N] or NULL; m [M, N] (ld ldm) for NRM_EPI_MUL */
 int nrm_gemm_nt(const float* x, int ldx, int M, const float* packed, int N, int K, const float* bias,
-                float* y, int ldy, float* z, int ldz, int epilogue, nrm_stream_t stream);
+                float* y, int ldy, float* z, int ldz, const float* m, int ldm, int epilogue, nrm_stream_t stream);
 /* C[i,j] = sum_r A[r,i] B[r,j]  (dW = dY^T X): writes nsplit TRANSPOSED partial slabs ws[s][j][ldws] and, if
  * colsum != NULL, colsum[s][i] = sum_r A[r,i] (the bias gradient); sum over s.  ldws % 4 == 0, ldws >= ncols_i */
 int nrm_gemm_tn_nsplit(int ncols_i, int ncols_j, int R);
 int nrm_gemm_tn(const float* A, int lda, int ncols_i, const float* B, int ldb, int ncols_j, int R,
                 float* ws, int ldws, float* colsum, nrm_stream_t stream);
 
+/* the split slabs ws[s][j][ldws] of nrm_gemm_tn / nrm_pwattn_bwd_contract summed over s and written where the gradient
+ * lives: out[i*out_istride + j*out_jstride] = sum_s ws[s][j][i]  (i < ni, j < nj; (nj, 1) strides give C[i,j] row-major,
+ * i.e. the transpose of a slab, (1, ld) a column block of a wider matrix ...).  out2 (optional) receives sign2 times the
+ * same value, stored (accumulate2 == 0) or added -- the t-h block of fc1's gradient (attention_model.py:81-86) is
+ * da_t - da_h.  vec [nsplit][ldws] (optional, the colsum slabs) -> vec_out[i] = sum_s vec[s][i]  (the bias gradient). */
+int nrm_slab_reduce(const float* ws, int nsplit, int nj, int ldws, int ni, float* out, long out_istride, long out_jstride,
+                    float* out2, long out2_istride, long out2_jstride, float sign2, int accumulate2,
+                    const float* vec, float* vec_out, nrm_stream_t stream);
+
 /* ---- BatchNorm1d over rows (reference models/user_model.py:18,32), N % 4 == 0, ld % 4 == 0.
  * nrm_colreduce mode 0: s0 += sum_r x;  1: s0 += sum_r (x-mean)^2;  2: s0 += sum_r dy, s1 += sum_r dy*(x-mean)*rstd */
 int nrm_colreduce(int mode, const float* x, const float* dy, const float* mean, const float* rstd,
                   float* s0, float* s1, int R, int N, int ld, nrm_stream_t stream);
+/* between the reductions (train mode): stage 0: out = mean = s/R, running = (1-momentum) running + momentum mean;
+ * stage 1: var = s/R, out = rstd = 1/sqrt(var + eps), running = (1-momentum) running + momentum var R/(R-1).
+ * running may be NULL. */
+int nrm_bn_finalize(int stage, const float* s, float* out, float* running, int R, int N, float momentum, float eps,
+                    nrm_stream_t stream);
+/* backward of the gate product y = g * e (models/user_model.py:33): dg = dy * e, de = dy * g; [R, N], N % 4 == 0 */
+int nrm_mul_bwd(const float* dy, int lddy, const float* g, int ldg, const float* e, int lde, float* dg, float* de, int ldo,
+                int R, int N, nrm_stream_t stream);
 int nrm_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                  float* y, int R, int N, int ld, nrm_stream_t stream);
 /* training != 0: dx = gamma*rstd*(dy - s0/R - xhat*s1/R) with s0,s1 from nrm_colreduce mode 2; else gamma*rstd*dy */

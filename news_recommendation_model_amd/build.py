@@ -24,6 +24,20 @@ def _hipcc():
     raise RuntimeError("hipcc not found (set HIPCC=/path/to/hipcc)")
 
 
+def sources_digest():
+    """sha256 over the kernel sources (csrc/* and the C header), in name order: what a profile under profiles/ is
+    stamped with (scripts/pmc_summary.py) and what bench.py compares before quoting a stored PMC figure -- the GPU box
+    has no .git, so the stamp is over file contents, not a commit id."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, "..", "include", "nrm_hotpath.h")]
+    for path in files:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True

@@ -153,20 +153,23 @@ int nrm_gemm_pack(const float* src, long row_stride, long col_stride, int nrows,
 }
 
 int nrm_gemm_nt(const float* x, int ldx, int M, const float* packed, int N, int K, const float* bias,
-                float* y, int ldy, float* z, int ldz, int epilogue, nrm_stream_t stream) {
+                float* y, int ldy, float* z, int ldz, const float* m, int ldm, int epilogue, nrm_stream_t stream) {
     if (!x || !packed || !y) return fail(NRM_EINVAL, "nrm_gemm_nt: null pointer");
     if (M < 0 || N <= 0 || K <= 0) return fail(NRM_EINVAL, "nrm_gemm_nt: M=%d N=%d K=%d", M, N, K);
     if (ldx % 4 || ldy % 4 || ldx < K || ldy < N || !al16(x) || !al16(y))
         return fail(NRM_EINVAL, "nrm_gemm_nt: ldx=%d ldy=%d must be multiples of 4 covering K=%d / N=%d, rows 16-B aligned", ldx, ldy, K, N);
     if (epilogue != NRM_EPI_BIAS && (!z || ldz % 4 || ldz < N || !al16(z)))
         return fail(NRM_EINVAL, "nrm_gemm_nt: epilogue %d needs z with ldz %% 4 == 0, ldz >= N", epilogue);
-    if (epilogue < 0 || epilogue > 2) return fail(NRM_EINVAL, "nrm_gemm_nt: epilogue=%d", epilogue);
+    if (epilogue < 0 || epilogue > 3) return fail(NRM_EINVAL, "nrm_gemm_nt: epilogue=%d", epilogue);
+    if (epilogue == NRM_EPI_MUL && (!m || ldm % 4 || ldm < N || !al16(m)))
+        return fail(NRM_EINVAL, "nrm_gemm_nt: NRM_EPI_MUL needs m with ldm %% 4 == 0, ldm >= N");
     if ((long)256 * (ldx > ldy ? ldx : ldy) * 4 >= (1L << 31)) return fail(NRM_EINVAL, "nrm_gemm_nt: leading dimension too large");
     const nrm::GemmNtPlan pl = nrm::gemm_nt_plan(N);
     nrm::GemmNtParams p;
     p.x = x; p.ldx = ldx; p.xcols = ldx; p.wp = packed; p.wp_bytes = (unsigned)(nrm_gemm_packed_floats(N, K) * 4);
     p.rows = pl.rows; p.bias = bias; p.N = N; p.y = y; p.ldy = ldy;
     p.z = epilogue == NRM_EPI_BIAS ? nullptr : z; p.ldz = epilogue == NRM_EPI_BIAS ? 4 : ldz;
+    p.m = epilogue == NRM_EPI_MUL ? m : nullptr; p.ldm = epilogue == NRM_EPI_MUL ? ldm : 4;
     p.M = M; p.kchunks = (K + 15) / 16;
     return check_hip(nrm::gemm_nt_launch(p, pl, epilogue, (hipStream_t)stream), "gemm_nt");
 }
@@ -195,6 +198,18 @@ int nrm_gemm_tn(const float* A, int lda, int ncols_i, const float* B, int ldb, i
     return check_hip(nrm::gemm_tn_launch(p, pl, (hipStream_t)stream), "gemm_tn");
 }
 
+int nrm_slab_reduce(const float* ws, int nsplit, int nj, int ldws, int ni, float* out, long out_istride, long out_jstride,
+                    float* out2, long out2_istride, long out2_jstride, float sign2, int accumulate2,
+                    const float* vec, float* vec_out, nrm_stream_t stream) {
+    if (!ws || !out) return fail(NRM_EINVAL, "nrm_slab_reduce: null pointer");
+    if (nsplit <= 0 || nj <= 0 || ni <= 0 || ldws < ni) return fail(NRM_EINVAL, "nrm_slab_reduce: nsplit=%d nj=%d ni=%d ldws=%d", nsplit, nj, ni, ldws);
+    if ((vec == nullptr) != (vec_out == nullptr)) return fail(NRM_EINVAL, "nrm_slab_reduce: vec and vec_out go together");
+    nrm::SlabReduceParams p;
+    p.ws = ws; p.nsplit = nsplit; p.nj = nj; p.ldws = ldws; p.ni = ni; p.out = out; p.ors = out_istride; p.ocs = out_jstride;
+    p.out2 = out2; p.ors2 = out2_istride; p.ocs2 = out2_jstride; p.sign2 = sign2; p.acc2 = accumulate2; p.vec = vec; p.vec_out = vec_out;
+    return check_hip(nrm::slab_reduce_launch(p, (hipStream_t)stream), "slab_reduce");
+}
+
 // ------------------------------------------------------------------------------------------- BatchNorm
 static int check_bn(const char* fn, int R, int N, int ld) {
     if (R < 0 || N <= 0 || N % 4 || ld % 4 || ld < N) return fail(NRM_EINVAL, "%s: R=%d N=%d ld=%d (N, ld multiples of 4)", fn, R, N, ld);
@@ -207,6 +222,22 @@ int nrm_colreduce(int mode, const float* x, const float* dy, const float* mean, 
     if (!x || !s0 || (mode >= 1 && !mean) || (mode == 2 && (!dy || !rstd || !s1)) || mode < 0 || mode > 2)
         return fail(NRM_EINVAL, "nrm_colreduce: bad argument for mode %d", mode);
     return check_hip(nrm::colred_launch(mode, x, dy, mean, rstd, s0, s1, R, N, ld, (hipStream_t)stream), "colreduce");
+}
+
+int nrm_bn_finalize(int stage, const float* s, float* out, float* running, int R, int N, float momentum, float eps,
+                    nrm_stream_t stream) {
+    if (!s || !out) return fail(NRM_EINVAL, "nrm_bn_finalize: null pointer");
+    if ((stage != 0 && stage != 1) || R <= 0 || N <= 0) return fail(NRM_EINVAL, "nrm_bn_finalize: stage=%d R=%d N=%d", stage, R, N);
+    return check_hip(nrm::bn_finalize_launch(stage, s, out, running, R, N, momentum, eps, (hipStream_t)stream), "bn_finalize");
+}
+
+int nrm_mul_bwd(const float* dy, int lddy, const float* g, int ldg, const float* e, int lde, float* dg, float* de, int ldo,
+                int R, int N, nrm_stream_t stream) {
+    if (!dy || !g || !e || !dg || !de) return fail(NRM_EINVAL, "nrm_mul_bwd: null pointer");
+    if (R < 0 || N <= 0 || N % 4 || lddy % 4 || ldg % 4 || lde % 4 || ldo % 4 || lddy < N || ldg < N || lde < N || ldo < N ||
+        !al16(dy) || !al16(g) || !al16(e) || !al16(dg) || !al16(de))
+        return fail(NRM_EINVAL, "nrm_mul_bwd: R=%d N=%d (N and leading dimensions multiples of 4, 16-byte aligned rows)", R, N);
+    return check_hip(nrm::mul_bwd_launch(dy, g, e, dg, de, R, N, lddy, ldg, lde, ldo, (hipStream_t)stream), "mul_bwd");
 }
 
 int nrm_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,

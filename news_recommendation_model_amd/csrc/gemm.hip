@@ -70,6 +70,8 @@ __global__ __launch_bounds__(256, WPE) void gemm_nt_kernel(const GemmNtParams p)
     const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(
         p.z ? p.z + (size_t)m0 * p.ldz : nullptr, 0, p.z ? rows_here * p.ldz * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? (p.N + 3) / 4 * 16 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(EPI == EPI_MUL ? p.m + (size_t)m0 * p.ldm : nullptr), 0, EPI == EPI_MUL ? rows_here * p.ldm * 4 : 0, 0x00020000);
 
     unsigned voff_x[MT];
 #pragma unroll
@@ -151,6 +153,11 @@ __global__ __launch_bounds__(256, WPE) void gemm_nt_kernel(const GemmNtParams p)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] = gelu_f(v[e]);
                 if (n < p.ldy) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb, 0);
+            } else if (EPI == EPI_MUL) {   // z = v (kept for backward), y = v * m
+                if (n < p.ldz) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_z, (unsigned)(rl * p.ldz + 4 * q) * 4u, nb, 0);
+                f32x4 mm = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (n < p.ldm) mm = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_m, (unsigned)(rl * p.ldm + 4 * q) * 4u, nb, 0));
+                if (n < p.ldy) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v * mm), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb, 0);
             } else {   // EPI_DGELU: y = acc * gelu'(z_saved)
                 f32x4 zz = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (n < p.ldz) zz = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_z, (unsigned)(rl * p.ldz + 4 * q) * 4u, nb, 0));
@@ -187,6 +194,7 @@ static hipError_t launch_nt(const GemmNtParams& p, const GemmNtPlan& pl, int epi
         case EPI_BIAS:  hipLaunchKernelGGL((gemm_nt_kernel<NT, MT, EPI_BIAS, WPE>), grid, block, 0, st, p); break;
         case EPI_GELU:  hipLaunchKernelGGL((gemm_nt_kernel<NT, MT, EPI_GELU, WPE>), grid, block, 0, st, p); break;
         case EPI_DGELU: hipLaunchKernelGGL((gemm_nt_kernel<NT, MT, EPI_DGELU, WPE>), grid, block, 0, st, p); break;
+        case EPI_MUL:   hipLaunchKernelGGL((gemm_nt_kernel<NT, MT, EPI_MUL, WPE>), grid, block, 0, st, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -343,6 +351,62 @@ hipError_t gemm_tn_launch(GemmTnParams p, const GemmTnPlan& pl, hipStream_t st) 
     const dim3 grid(pl.nti * pl.ntj, (pl.nsplit + 3) / 4), block(256);
     if (pl.T == 5) hipLaunchKernelGGL((gemm_tn_kernel<5, 5>), grid, block, 0, st, p);
     else           hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), grid, block, 0, st, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// slab reduction: the partial slabs ws[s][j][i] of gemm_tn / the attention dW_p pass -> the gradient tensor itself
+// (sum over s + transpose + strided placement in ONE launch; was ATen sum(dim=0).t() + cat: 24 reduce launches and a
+// concat per step).  blockDim (32, 8); a block owns a 32(i) x 32(j) tile: reads run along i (the slab's fast index),
+// the tile is transposed through LDS and written along j.  blockIdx.y == gridDim.y - 1 sums the bias-gradient vectors.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceParams p) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int nbi = (p.ni + 31) / 32;
+    if (blockIdx.y == gridDim.y - 1) {                                 // vector leg (db = sum of per-split column sums)
+        if (!p.vec) return;
+        const int i = blockIdx.x * 256 + ty * 32 + tx;
+        if (blockIdx.x * 256 < p.ni && i < p.ni) {
+            float a = 0.f;
+            for (int s = 0; s < p.nsplit; ++s) a += p.vec[(size_t)s * p.ldws + i];
+            p.vec_out[i] = a;
+        }
+        return;
+    }
+    if ((int)blockIdx.x >= nbi * ((p.nj + 31) / 32)) return;            // grid.x is sized for the longer of the two legs
+    const int i0 = (blockIdx.x % nbi) * 32, j0 = (blockIdx.x / nbi) * 32;
+    const size_t slab = (size_t)p.nj * p.ldws;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = j0 + ty + 8 * r, i = i0 + tx;
+        float a = 0.f;
+        if (i < p.ni && j < p.nj) {
+            const float* src = p.ws + (size_t)j * p.ldws + i;
+            for (int s = 0; s < p.nsplit; ++s) a += src[s * slab];
+        }
+        tile[ty + 8 * r][tx] = a;                                      // tile[j][i]
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + ty + 8 * r, j = j0 + tx;
+        if (i < p.ni && j < p.nj) {
+            const float v = tile[tx][ty + 8 * r];
+            p.out[i * p.ors + j * p.ocs] = v;
+            if (p.out2) {
+                float* o2 = p.out2 + i * p.ors2 + j * p.ocs2;
+                *o2 = p.acc2 ? *o2 + p.sign2 * v : p.sign2 * v;
+            }
+        }
+    }
+}
+
+hipError_t slab_reduce_launch(const SlabReduceParams& p, hipStream_t st) {
+    if (p.ni <= 0 || p.nj <= 0) return hipSuccess;
+    const int nbi = (p.ni + 31) / 32, nbj = (p.nj + 31) / 32;
+    int gx = nbi * nbj;
+    if (p.vec && (p.ni + 255) / 256 > gx) gx = (p.ni + 255) / 256;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx, 2), dim3(32, 8), 0, st, p);
     return hipGetLastError();
 }
 

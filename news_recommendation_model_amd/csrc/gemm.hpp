@@ -4,7 +4,7 @@
 
 namespace nrm {
 
-enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_DGELU = 2 };
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_MUL = 3 };
 
 struct GemmNtParams {
     const float* x; int ldx, xcols;       // [M, ldx]; xcols = readable floats per row (<= ldx)
@@ -12,7 +12,8 @@ struct GemmNtParams {
     int rows;                             // padded packed rows = nchunks * NT * 16
     const float* bias; int N;             // [N] or nullptr
     float* y; int ldy;                    // [M, ldy]
-    float* z; int ldz;                    // EPI_GELU: pre-activation out, EPI_DGELU: pre-activation in
+    float* z; int ldz;                    // EPI_GELU: pre-activation out, EPI_DGELU: pre-activation in, EPI_MUL: un-multiplied out
+    const float* m; int ldm;              // EPI_MUL: y = (x W^T + bias) * m   (the gate of user_model.py:33)
     int M, kchunks;
 };
 struct GemmNtPlan { int NT, MT, nchunks, rows; };
@@ -32,5 +33,16 @@ struct GemmTnParams {
 struct GemmTnPlan { int T, nti, ntj, nsplit, rps; };
 GemmTnPlan gemm_tn_plan(int ncols_i, int ncols_j, int R, int target_waves);
 hipError_t gemm_tn_launch(GemmTnParams p, const GemmTnPlan& pl, hipStream_t st);
+
+// out[i*ors + j*ocs] = sum_s ws[s][j][i] (i < ni, j < nj): the split slabs of gemm_tn / the dW_p pass summed and
+// written where the gradient lives (any strides: straight or transposed, or a column block of a wider matrix);
+// out2 (optional) gets sign2 * the same value, stored (acc2 == 0) or added (acc2 != 0); vec_out[i] = sum_s vec[s][i].
+struct SlabReduceParams {
+    const float* ws; int nsplit, nj, ldws, ni;
+    float* out; long ors, ocs;
+    float* out2; long ors2, ocs2; float sign2; int acc2;
+    const float* vec; float* vec_out;     // [nsplit][ldws] -> [ni], or nullptr
+};
+hipError_t slab_reduce_launch(const SlabReduceParams& p, hipStream_t st);
 
 }  // namespace nrm

@@ -95,6 +95,49 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ x
     }
 }
 
+// train-mode statistics between the column reductions (was ~8 tiny ATen launches per BatchNorm call):
+//   stage 0: mean = s0 / R;  running_mean = (1 - momentum) running_mean + momentum mean
+//   stage 1: var = s1 / R (biased, normalises);  rstd = 1/sqrt(var + eps);
+//            running_var = (1 - momentum) running_var + momentum var R/(R-1)      (unbiased, nn.BatchNorm1d)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(int stage, const float* __restrict__ s, float* __restrict__ out,
+                                                          float* __restrict__ running, int R, int N, float momentum, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float v = s[i] / (float)R;
+    if (stage == 0) {
+        out[i] = v;
+        if (running) running[i] = (1.0f - momentum) * running[i] + momentum * v;
+    } else {
+        out[i] = 1.0f / sqrtf(v + eps);
+        if (running) running[i] = (1.0f - momentum) * running[i] + momentum * v * ((float)R / (float)(R > 1 ? R - 1 : 1));
+    }
+}
+
+hipError_t bn_finalize_launch(int stage, const float* s, float* out, float* running, int R, int N, float momentum, float eps,
+                              hipStream_t st) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, st, stage, s, out, running, R, N, momentum, eps);
+    return hipGetLastError();
+}
+
+// backward of the gate product y = g * e (reference models/user_model.py:33): dg = dy * e, de = dy * g in one pass
+__global__ __launch_bounds__(256) void mul_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ g,
+                                                      const float* __restrict__ e, float* __restrict__ dg,
+                                                      float* __restrict__ de, long R, int N, int lddy, int ldg, int lde,
+                                                      int ldo) {
+    const int n4 = N >> 2;
+    const long total = R * n4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / n4;
+        const int col = (int)(i - r * n4) * 4;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + r * lddy + col);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + r * ldg + col);
+        const f32x4 ev = *reinterpret_cast<const f32x4*>(e + r * lde + col);
+        *reinterpret_cast<f32x4*>(dg + r * ldo + col) = d * ev;
+        *reinterpret_cast<f32x4*>(de + r * ldo + col) = d * gv;
+    }
+}
+
 hipError_t colred_launch(int mode, const float* x, const float* dy, const float* mean, const float* rstd,
                          float* s0, float* s1, int R, int N, int ld, hipStream_t st) {
     if (R <= 0) return hipSuccess;
@@ -113,6 +156,13 @@ hipError_t bn_apply_launch(const float* x, const float* mean, const float* rstd,
                            float* y, long R, int N, int ld, hipStream_t st) {
     if (R <= 0) return hipSuccess;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(R * (N >> 2))), dim3(256), 0, st, x, mean, rstd, gamma, beta, y, R, N, ld);
+    return hipGetLastError();
+}
+
+hipError_t mul_bwd_launch(const float* dy, const float* g, const float* e, float* dg, float* de, long R, int N,
+                          int lddy, int ldg, int lde, int ldo, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mul_bwd_kernel, dim3(ew_blocks(R * (N >> 2))), dim3(256), 0, st, dy, g, e, dg, de, R, N, lddy, ldg, lde, ldo);
     return hipGetLastError();
 }
 

@@ -9,4 +9,8 @@ hipError_t bn_apply_launch(const float* x, const float* mean, const float* rstd,
                            float* y, long R, int N, int ld, hipStream_t st);
 hipError_t bn_bwd_launch(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
                          const float* s0, const float* s1, float* dx, long R, int N, int ld, int training, hipStream_t st);
+hipError_t bn_finalize_launch(int stage, const float* s, float* out, float* running, int R, int N, float momentum, float eps,
+                              hipStream_t st);
+hipError_t mul_bwd_launch(const float* dy, const float* g, const float* e, float* dg, float* de, long R, int N,
+                          int lddy, int ldg, int lde, int ldo, hipStream_t st);
 }  // namespace nrm

@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import torch
 
-from . import native, ops
+from . import ops
 
 
 @torch.no_grad()
@@ -48,15 +48,7 @@ def predict(models, batch):
 def row_auc_top1(scores, labels, live=None):
     """Per-row AUC [B] (fp32, -1 where a row has one class) and top-1 hit [B] (int32) on the device."""
     ops._require_gpu(scores, labels)
-    s = scores.to(torch.float32).contiguous()
-    y = labels.to(torch.float32).contiguous()
-    B, T = s.shape
-    ln = live.to(torch.int32).contiguous() if live is not None else None
-    auc = torch.empty(B, dtype=torch.float32, device=s.device)
-    top1 = torch.empty(B, dtype=torch.int32, device=s.device)
-    native.call("nrm_row_auc", native.ptr(s), native.ptr(y), native.ptr(ln) if ln is not None else None, B, T,
-                native.ptr(auc), native.ptr(top1), native.stream_ptr())
-    return auc, top1
+    return ops.row_auc(scores, labels, live)                    # torch.ops.nrm.row_auc -> C ABI nrm_row_auc
 
 
 @torch.no_grad()

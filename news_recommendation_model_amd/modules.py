@@ -41,12 +41,17 @@ class MLP(nn.Module):
         self.activation = _ACTIVATIONS.get(str(activation_type).lower(), nn.GELU)()
 
     def forward(self, x):
+        return self.forward_times(x, None)
+
+    def forward_times(self, x, mul):
+        """forward(x) [* mul]: the product (the gate of models/user_model.py:33) rides in fc2's GEMM epilogue."""
         ops._require_gpu(x)
         if isinstance(self.activation, nn.GELU) and self.activation.approximate == "none":
             # one autograd node: bias + exact GELU fused into fc1's GEMM, GELU' fused into the backward GEMM of fc2
-            return ops.mlp_gelu(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+            return ops.mlp_gelu(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, mul=mul)
         hidden = self.activation(ops.linear(x, self.fc1.weight, self.fc1.bias))
-        return ops.linear(hidden, self.fc2.weight, self.fc2.bias)
+        y = ops.linear(hidden, self.fc2.weight, self.fc2.bias)
+        return y if mul is None else y * mul
 
 
 def _scores(mlp: MLP, target, history):
@@ -191,7 +196,7 @@ class UserModel(nn.Module):
         e = torch.cat((eu_H, eu_L, ec), dim=2)
         B, T, N = e.shape
         rows = e.reshape(B * T, N)
-        gated = self.gate(ops.batch_norm(rows, self.bn)) * rows     # the gate multiplies the RAW concat
+        gated = self.gate.forward_times(ops.batch_norm(rows, self.bn), rows)     # the gate multiplies the RAW concat
         return self.out_mlp(self.mlp(gated)).reshape(B, T)
 
     def loss(self, id, out, label, alpha=0.95):

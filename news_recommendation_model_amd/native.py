@@ -28,7 +28,11 @@ SIGNATURES = {
     "nrm_pwattn_bwd_contract": (_c_i, [_c_fp] * 4 + [_c_i] + [_c_fp] * 3 + [_c_i] * 5 + [_c_fp]),
     "nrm_gemm_packed_floats": (_c_l, [_c_i, _c_i]),
     "nrm_gemm_pack": (_c_i, [_c_fp, _c_l, _c_l, _c_i, _c_i, _c_fp, _c_fp]),
-    "nrm_gemm_nt": (_c_i, [_c_fp, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_fp, _c_fp, _c_i, _c_fp, _c_i, _c_i, _c_fp]),
+    "nrm_gemm_nt": (_c_i, [_c_fp, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_fp, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_i, _c_fp]),
+    "nrm_slab_reduce": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_l, _c_l, _c_fp, _c_l, _c_l, ctypes.c_float, _c_i,
+                               _c_fp, _c_fp, _c_fp]),
+    "nrm_bn_finalize": (_c_i, [_c_i, _c_fp, _c_fp, _c_fp, _c_i, _c_i, ctypes.c_float, ctypes.c_float, _c_fp]),
+    "nrm_mul_bwd": (_c_i, [_c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_fp]),
     "nrm_gemm_tn_nsplit": (_c_i, [_c_i, _c_i, _c_i]),
     "nrm_gemm_tn": (_c_i, [_c_fp, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_fp]),
     "nrm_colreduce": (_c_i, [_c_i] + [_c_fp] * 6 + [_c_i] * 3 + [_c_fp]),

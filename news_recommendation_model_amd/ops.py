@@ -1,8 +1,14 @@
-"""Autograd-visible operators over the C-ABI kernels (include/nrm_hotpath.h).
+"""The hot-path operators: ``torch.library`` custom ops (namespace ``nrm``) over the C-ABI kernels of
+include/nrm_hotpath.h, plus the differentiable Python entry points the Modules call.
 
-``pointwise_attention_scores`` replaces the body of the reference
-``PointwiseAttentionExpanded.forward`` (models/attention_model.py:52-97).  Inputs must live on an
-MI355X; anything else raises -- there is no CPU path in the product.
+Layering: ``modules.py`` -> functions below -> ``torch.ops.nrm.*`` (schema, fake-tensor shape function,
+autograd formula registered with ``torch.library``) -> ``native.call`` (ctypes) -> ``libnrm_hotpath.so``.  Every op has a
+CUDA (= ROCm) implementation only: inputs must live on an MI355X, there is no CPU kernel and no eager fallback.
+
+``torch.ops.nrm.pwattn_fwd`` replaces the body of the reference ``PointwiseAttentionExpanded.forward``
+(models/attention_model.py:52-97); ``mlp_gelu_fwd`` the reference ``MLP.forward`` (:29-32); ``batch_norm_fwd``,
+``softmax_bce_loss`` the head and loss of models/user_model.py:31-43; ``frontend_fwd`` the slicing/embedding front end of
+models/user_invariant_interest_model.py:50-79; ``weighted_pool_fwd`` its pool (:86-87).
 """
 from __future__ import annotations
 
@@ -10,10 +16,12 @@ import torch
 
 from . import native
 
+EPI_BIAS, EPI_GELU, EPI_DGELU, EPI_MUL = 0, 1, 2, 3
+
 
 def _require_gpu(*tensors):
     for t in tensors:
-        if not t.is_cuda:
+        if t is not None and not t.is_cuda:
             raise RuntimeError(
                 "news_recommendation_model_amd: the hot path only runs on an MI355X (ROCm) device; got a "
                 f"{t.device} tensor. Move the model and the inputs to 'cuda' (there is no CPU fallback).")
@@ -36,108 +44,6 @@ def _degenerate(shape, *deps):
     return out
 
 
-class _PointwiseAttentionScores(torch.autograd.Function):
-    """s[b,t,h] = fc2(GELU(fc1(cat[h, t, t-h, t*h]))) with fc1 = [W_h|W_t|W_d|W_p] re-associated as
-    z = h(W_h-W_d)^T + b1 + t(W_t+W_d)^T + sum_d W_p[:,d] t_d h_d  (SURVEY.md §8 a7)."""
-
-    @staticmethod
-    def forward(ctx, t, h, w1, b1, w2, b2):
-        _require_gpu(t, h, w1, b1, w2, b2)
-        B, T, D = t.shape
-        H = h.shape[1]
-        if h.shape[0] != B or h.shape[2] != D or tuple(w1.shape) != (D, 4 * D):
-            raise RuntimeError(f"pointwise attention: target {tuple(t.shape)}, history {tuple(h.shape)}, "
-                               f"fc1 {tuple(w1.shape)} do not agree")
-        t, h, w1, b1 = _f32c(t), _f32c(h), _f32c(w1), _f32c(b1)
-        w2v, b2 = _f32c(w2).reshape(-1), _f32c(b2).reshape(-1)
-        w_h, w_t, w_d = w1[:, :D], w1[:, D:2 * D], w1[:, 2 * D:3 * D]
-        a_h = w_h - w_d
-        a_t = w_t + w_d
-        u, _ = _gemm_nt(h.reshape(B * H, D), a_h.contiguous(), D, 1, D, D, b1, 0)      # [B*H, D]
-        v, _ = _gemm_nt(t.reshape(B * T, D), a_t.contiguous(), D, 1, D, D, None, 0)    # [B*T, D]
-        need_grad = any(ctx.needs_input_grad) and torch.is_grad_enabled()      # no [B,T,H,D] buffer under no_grad / eval
-        st = native.stream_ptr()
-        packed = torch.empty(native.load().nrm_pwattn_packed_floats(D), dtype=torch.float32, device=t.device)
-        native.call("nrm_pwattn_pack_wp", native.ptr(w1), 4 * D, D, native.ptr(packed), st)
-        s = torch.empty(B, T, H, dtype=torch.float32, device=t.device)
-        z = torch.empty(B, T, H, D, dtype=torch.float32, device=t.device) if need_grad else None
-        native.call("nrm_pwattn_fwd", native.ptr(t), native.ptr(h), native.ptr(u), native.ptr(v),
-                    native.ptr(packed), native.ptr(w2v), native.ptr(b2),
-                    native.ptr(z) if z is not None else None, native.ptr(s), B, T, H, D, st)
-        if need_grad:
-            ctx.save_for_backward(t, h, w1, w2v, z)
-            ctx.w2_shape = tuple(w2.shape)
-            ctx.z_consumed = False
-        return s
-
-    @staticmethod
-    def backward(ctx, ds):
-        if ctx.z_consumed:
-            # the saved pre-activation is overwritten in place by dz below (2.46 GB at C3: no second copy), so the
-            # graph can be walked once; the reference's autograd would allow retain_graph=True here
-            raise RuntimeError("pointwise attention: backward through this graph a second time is not supported "
-                               "(the saved pre-activation buffer was consumed by the first backward); "
-                               "re-run the forward instead of retain_graph=True")
-        ctx.z_consumed = True
-        t, h, w1, w2v, z = ctx.saved_tensors
-        B, T, D = t.shape
-        H = h.shape[1]
-        st = native.stream_ptr()
-        ds = _f32c(ds)
-        dw2 = torch.zeros(D, dtype=torch.float32, device=t.device)
-        # one pass over z: z -> dz in place (the saved tensor is consumed: a second backward through it is
-        # not supported), du = sum_t dz, dv = sum_h dz, dw2
-        du = torch.empty(B, H, D, dtype=torch.float32, device=t.device)
-        dv = torch.empty(B, T, D, dtype=torch.float32, device=t.device)
-        native.call("nrm_pwattn_bwd_dz", native.ptr(z), native.ptr(ds), native.ptr(w2v), native.ptr(dw2),
-                    native.ptr(du), native.ptr(dv), B, T, H, D, st)
-        dz = z
-        db2 = ds.sum().reshape(1)
-        w_h, w_t, w_d = w1[:, :D], w1[:, D:2 * D], w1[:, 2 * D:3 * D]
-        a_h = w_h - w_d
-        a_t = w_t + w_d
-        du2, dv2 = du.reshape(B * H, D), dv.reshape(B * T, D)
-        da_h, db1 = _gemm_tn(du2, h.reshape(B * H, D), True)      # du^T h, and db1 = column sums of du
-        da_t, _ = _gemm_tn(dv2, t.reshape(B * T, D), False)
-        a_hc, a_tc = a_h.contiguous(), a_t.contiguous()
-        dh = _gemm_nt(du2, a_hc, 1, D, D, D, None, 0)[0].reshape(B, H, D).contiguous()     # du A_h
-        dt = _gemm_nt(dv2, a_tc, 1, D, D, D, None, 0)[0].reshape(B, T, D).contiguous()     # dv A_t
-        nsplit = native.load().nrm_pwattn_bwd_nsplit(B, T, H, D)
-        ws = torch.empty(nsplit, D, D, dtype=torch.float32, device=t.device)
-        wp = w1[:, 3 * D:]                                   # view, row stride 4D
-        # two launches: (b,t)-grouped -> dt + dW_p slabs, (b,h)-grouped -> dh (issued separately so that
-        # bench.py can time each kernel with its own event pair)
-        for passes, tag in ((1, "pwattn_bwd_e_bt"), (2, "pwattn_bwd_e_bh")):
-            native.call("nrm_pwattn_bwd_contract", native.ptr(dz), native.ptr(t), native.ptr(h),
-                        native.ptr(wp), 4 * D, native.ptr(dt), native.ptr(dh), native.ptr(ws), B, T, H, D,
-                        passes, st, tag=tag)
-        dwp = ws.sum(dim=0).t()                             # slabs hold dW_p^T ([d][k])
-        dw1 = torch.cat([da_h, da_t, da_t - da_h, dwp], dim=1)
-        return dt, dh, dw1, db1, dw2.reshape(ctx.w2_shape), db2
-
-
-def pointwise_attention_scores(target, history, fc1_weight, fc1_bias, fc2_weight, fc2_bias):
-    """[B,T,D] x [B,H,D] -> [B,T,H] scores (fp32).
-
-    The kernels need the feature width to be a multiple of 4 (float4 rows).  Any other D is zero-padded here with
-    differentiable ops: padded features contribute exactly 0 to every term (their fc1 rows/columns and fc2 weights
-    are 0, gelu(0) = 0), and autograd slices the gradients back."""
-    D = target.shape[-1]
-    if target.shape[0] * target.shape[1] * history.shape[1] == 0:
-        return _degenerate((target.shape[0], target.shape[1], history.shape[1]), target, history, fc1_weight, fc1_bias,
-                           fc2_weight, fc2_bias)
-    if D % 4 == 0:
-        return _PointwiseAttentionScores.apply(target, history, fc1_weight, fc1_bias, fc2_weight, fc2_bias)
-    _require_gpu(target, history, fc1_weight)
-    P = _pad4(D) - D
-    pad = torch.nn.functional.pad
-    blocks = [pad(fc1_weight[:, i * D:(i + 1) * D], (0, P, 0, P)) for i in range(4)]     # [D4, D4] each
-    return _PointwiseAttentionScores.apply(pad(target.to(torch.float32), (0, P)), pad(history.to(torch.float32), (0, P)),
-                                           torch.cat(blocks, dim=1), pad(fc1_bias, (0, P)),
-                                           pad(fc2_weight.reshape(1, D), (0, P)), fc2_bias)
-
-
-# ------------------------------------------------------------------------------------------------ dense layers
 def _pad4(n):
     return (n + 3) // 4 * 4
 
@@ -153,7 +59,13 @@ def _rows(x):
     return buf[:, :x.shape[1]]
 
 
-def _gemm_nt(x, w_src, row_stride, col_stride, n_out, k_red, bias, epilogue, z=None):
+def _padded_empty(like, rows, cols):
+    """[rows, cols] fp32 view of a fresh [rows, pad4(cols)] buffer (the layout every kernel output uses)."""
+    return torch.empty(rows, _pad4(cols), dtype=torch.float32, device=like.device)[:, :cols]
+
+
+# ------------------------------------------------------------------------------------------------ GEMM plumbing
+def _gemm_nt(x, w_src, row_stride, col_stride, n_out, k_red, bias, epilogue, z=None, m=None):
     """y[M, n_out] = epilogue(x[M, k_red] * Wlogical^T), Wlogical[r, c] = w_src[r*row_stride + c*col_stride]."""
     lib = native.load()
     st = native.stream_ptr()
@@ -162,18 +74,18 @@ def _gemm_nt(x, w_src, row_stride, col_stride, n_out, k_red, bias, epilogue, z=N
     native.call("nrm_gemm_pack", native.ptr(w_src), row_stride, col_stride, n_out, k_red, native.ptr(packed), st)
     ldy = _pad4(n_out)
     y = torch.empty(M, ldy, dtype=torch.float32, device=x.device)
-    if epilogue == 1:
+    if epilogue in (EPI_GELU, EPI_MUL):
         z = torch.empty(M, ldy, dtype=torch.float32, device=x.device)
     native.call("nrm_gemm_nt", native.ptr(x), x.stride(0), M, native.ptr(packed), n_out, k_red,
                 native.ptr(bias) if bias is not None else None, native.ptr(y), ldy,
-                native.ptr(z) if z is not None else None, z.stride(0) if z is not None else 0, epilogue, st)
-    return y[:, :n_out], (z[:, :n_out] if epilogue == 1 else None)
+                native.ptr(z) if z is not None else None, z.stride(0) if z is not None else 0,
+                native.ptr(m) if m is not None else None, m.stride(0) if m is not None else 0, epilogue, st)
+    return y[:, :n_out], (z[:, :n_out] if epilogue in (EPI_GELU, EPI_MUL) else None)
 
 
-def _gemm_tn(a, b, want_colsum):
-    """(sum_r a[r,i] b[r,j]) as [ni, nj], and optionally sum_r a[r,i]."""
+def _gemm_tn_slabs(a, b, want_colsum):
+    """Partial slabs of (sum_r a[r,i] b[r,j]): ws[s][j][ldws] (TRANSPOSED) and the per-split column sums of a."""
     lib = native.load()
-    st = native.stream_ptr()
     R, ni = a.shape
     nj = b.shape[1]
     nsplit = lib.nrm_gemm_tn_nsplit(ni, nj, R)
@@ -181,42 +93,259 @@ def _gemm_tn(a, b, want_colsum):
     ws = torch.empty(nsplit, nj, ldws, dtype=torch.float32, device=a.device)
     cs = torch.empty(nsplit, ldws, dtype=torch.float32, device=a.device) if want_colsum else None
     native.call("nrm_gemm_tn", native.ptr(a), a.stride(0), ni, native.ptr(b), b.stride(0), nj, R,
-                native.ptr(ws), ldws, native.ptr(cs) if cs is not None else None, st)
-    c = ws.sum(dim=0)[:, :ni].t()
-    return c, (cs.sum(dim=0)[:ni] if want_colsum else None)
+                native.ptr(ws), ldws, native.ptr(cs) if cs is not None else None, native.stream_ptr())
+    return ws, cs, nsplit, ldws
 
 
-class _Linear(torch.autograd.Function):
-    """y = act(x W^T + b) for a 2-D x; act in {none, exact GELU}.  Forward and both gradients run on the
-    fp32 MFMA GEMM kernels (csrc/gemm.hip)."""
+def _slab_reduce(ws, nsplit, nj, ldws, ni, out, out_is, out_js, out2=None, out2_is=0, out2_js=0, sign2=0.0, acc2=False,
+                 vec=None, vec_out=None):
+    native.call("nrm_slab_reduce", native.ptr(ws), nsplit, nj, ldws, ni, native.ptr(out), out_is, out_js,
+                native.ptr(out2) if out2 is not None else None, out2_is, out2_js, float(sign2), 1 if acc2 else 0,
+                native.ptr(vec) if vec is not None else None, native.ptr(vec_out) if vec_out is not None else None,
+                native.stream_ptr())
 
-    @staticmethod
-    def forward(ctx, x, weight, bias, gelu):
-        _require_gpu(x, weight)
-        x = _rows(x)
-        w = _f32c(weight)
-        N, K = w.shape
-        if x.shape[1] != K:
-            raise RuntimeError(f"linear: input has {x.shape[1]} features, weight expects {K}")
-        b = _f32c(bias) if bias is not None else None
-        y, z = _gemm_nt(x, w, K, 1, N, K, b, 1 if gelu else 0)
-        ctx.save_for_backward(x, w, z)
-        ctx.has_bias = bias is not None
-        return y
 
-    @staticmethod
-    def backward(ctx, dy):
-        x, w, z = ctx.saved_tensors
-        N, K = w.shape
-        if z is not None:
-            dy = torch.ops.aten.gelu_backward(dy, z)            # exact-erf GELU' (elementwise)
-        dy = _rows(dy)
-        dx = dw = db = None
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = _gemm_tn(dy, x, ctx.has_bias)              # dW[n,k] = sum_m dy[m,n] x[m,k]
-        if ctx.needs_input_grad[0]:
-            dx, _ = _gemm_nt(dy, w, 1, K, K, N, None, 0)        # dX = dY W : rows of the packed operand = k
-        return dx, dw, (db if ctx.has_bias else None), None
+def _gemm_tn(a, b, want_colsum):
+    """(sum_r a[r,i] b[r,j]) as a contiguous [ni, nj], and optionally sum_r a[r,i]: the split-M GEMM plus ONE
+    reduce+transpose launch that writes the gradient in place (no ATen sum/t/contiguous)."""
+    ni, nj = a.shape[1], b.shape[1]
+    ws, cs, nsplit, ldws = _gemm_tn_slabs(a, b, want_colsum)
+    c = torch.empty(ni, nj, dtype=torch.float32, device=a.device)
+    colsum = torch.empty(ni, dtype=torch.float32, device=a.device) if want_colsum else None
+    _slab_reduce(ws, nsplit, nj, ldws, ni, c, nj, 1, vec=cs, vec_out=colsum)
+    return c, colsum
+
+
+# ------------------------------------------------------------------------------------------------ op registry
+_LIB = torch.library.Library("nrm", "DEF")
+
+
+def _op(name, schema, impl, fake):
+    _LIB.define(name + schema)
+    _LIB.impl(name, impl, "CUDA")
+    torch.library.register_fake("nrm::" + name, fake, lib=_LIB)
+    return getattr(torch.ops.nrm, name)
+
+
+# ------------------------------------------------------------------------------------------------ pointwise attention
+def _pwattn_fwd_impl(t, h, w1, b1, w2, b2, save_z):
+    """s[b,t,h] = fc2(GELU(fc1(cat[h, t, t-h, t*h]))) with fc1 = [W_h|W_t|W_d|W_p] re-associated as
+    z = h(W_h-W_d)^T + b1 + t(W_t+W_d)^T + sum_d W_p[:,d] t_d h_d  (SURVEY.md §8 a7)."""
+    _require_gpu(t, h, w1, b1, w2, b2)
+    B, T, D = t.shape
+    H = h.shape[1]
+    if h.shape[0] != B or h.shape[2] != D or tuple(w1.shape) != (D, 4 * D) or D % 4:
+        raise RuntimeError(f"pointwise attention: target {tuple(t.shape)}, history {tuple(h.shape)}, "
+                           f"fc1 {tuple(w1.shape)} do not agree (feature width must be a multiple of 4)")
+    t, h, w1, b1 = _f32c(t), _f32c(h), _f32c(w1), _f32c(b1)
+    w2v, b2 = _f32c(w2).reshape(-1), _f32c(b2).reshape(-1)
+    w_h, w_t, w_d = w1[:, :D], w1[:, D:2 * D], w1[:, 2 * D:3 * D]
+    a_h = (w_h - w_d).contiguous()
+    a_t = (w_t + w_d).contiguous()
+    u, _ = _gemm_nt(h.reshape(B * H, D), a_h, D, 1, D, D, b1, EPI_BIAS)       # [B*H, D]
+    v, _ = _gemm_nt(t.reshape(B * T, D), a_t, D, 1, D, D, None, EPI_BIAS)     # [B*T, D]
+    st = native.stream_ptr()
+    packed = torch.empty(native.load().nrm_pwattn_packed_floats(D), dtype=torch.float32, device=t.device)
+    native.call("nrm_pwattn_pack_wp", native.ptr(w1), 4 * D, D, native.ptr(packed), st)
+    s = torch.empty(B, T, H, dtype=torch.float32, device=t.device)
+    z = torch.empty((B, T, H, D) if save_z else (0,), dtype=torch.float32, device=t.device)
+    native.call("nrm_pwattn_fwd", native.ptr(t), native.ptr(h), native.ptr(u), native.ptr(v),
+                native.ptr(packed), native.ptr(w2v), native.ptr(b2),
+                native.ptr(z) if save_z else None, native.ptr(s), B, T, H, D, st)
+    return s, z
+
+
+def _pwattn_fwd_fake(t, h, w1, b1, w2, b2, save_z):
+    B, T, D = t.shape
+    H = h.shape[1]
+    return (t.new_empty((B, T, H), dtype=torch.float32),
+            t.new_empty((B, T, H, D) if save_z else (0,), dtype=torch.float32))
+
+
+pwattn_fwd = _op("pwattn_fwd", "(Tensor t, Tensor h, Tensor fc1_weight, Tensor fc1_bias, Tensor fc2_weight, Tensor fc2_bias, "
+                 "bool save_z) -> (Tensor, Tensor)", _pwattn_fwd_impl, _pwattn_fwd_fake)
+
+
+def _pwattn_bwd_impl(ds, t, h, w1, w2, z):
+    """All gradients of one attention from ds [B,T,H] and the saved pre-activation z [B,T,H,D], which is overwritten
+    in place by dz (schema: Tensor(a!))."""
+    _require_gpu(ds, t, h, w1, w2, z)
+    B, T, D = t.shape
+    H = h.shape[1]
+    st = native.stream_ptr()
+    t, h, w1, ds = _f32c(t), _f32c(h), _f32c(w1), _f32c(ds)
+    w2v = _f32c(w2).reshape(-1)
+    dev = t.device
+    dw2 = torch.zeros(D, dtype=torch.float32, device=dev)
+    # one pass over z: z -> dz in place, du = sum_t dz, dv = sum_h dz, dw2
+    du = torch.empty(B, H, D, dtype=torch.float32, device=dev)
+    dv = torch.empty(B, T, D, dtype=torch.float32, device=dev)
+    native.call("nrm_pwattn_bwd_dz", native.ptr(z), native.ptr(ds), native.ptr(w2v), native.ptr(dw2),
+                native.ptr(du), native.ptr(dv), B, T, H, D, st)
+    dz = z
+    db2 = ds.sum().reshape(1)
+    w_h, w_t, w_d = w1[:, :D], w1[:, D:2 * D], w1[:, 2 * D:3 * D]
+    a_h = (w_h - w_d).contiguous()
+    a_t = (w_t + w_d).contiguous()
+    du2, dv2 = du.reshape(B * H, D), dv.reshape(B * T, D)
+    # fc1 gradient [D, 4D] = [da_h | da_t | da_t - da_h | dW_p]: every block is written in place by a slab reduction
+    dw1 = torch.empty(D, 4 * D, dtype=torch.float32, device=dev)
+    db1 = torch.empty(D, dtype=torch.float32, device=dev)
+    ws, cs, ns, ldws = _gemm_tn_slabs(du2, h.reshape(B * H, D), True)               # du^T h, db1 = column sums of du
+    _slab_reduce(ws, ns, D, ldws, D, dw1, 4 * D, 1, out2=dw1[:, 2 * D:], out2_is=4 * D, out2_js=1, sign2=-1.0, acc2=False,
+                 vec=cs, vec_out=db1)
+    ws, _, ns, ldws = _gemm_tn_slabs(dv2, t.reshape(B * T, D), False)
+    _slab_reduce(ws, ns, D, ldws, D, dw1[:, D:], 4 * D, 1, out2=dw1[:, 2 * D:], out2_is=4 * D, out2_js=1, sign2=1.0, acc2=True)
+    dh = _gemm_nt(du2, a_h, 1, D, D, D, None, EPI_BIAS)[0].reshape(B, H, D)        # du A_h   (D % 4 == 0: contiguous)
+    dt = _gemm_nt(dv2, a_t, 1, D, D, D, None, EPI_BIAS)[0].reshape(B, T, D)        # dv A_t
+    nsplit = native.load().nrm_pwattn_bwd_nsplit(B, T, H, D)
+    wsp = torch.empty(nsplit, D, D, dtype=torch.float32, device=dev)
+    wp = w1[:, 3 * D:]                                   # view, row stride 4D
+    # two launches: (b,t)-grouped -> dt + dW_p slabs, (b,h)-grouped -> dh (issued separately so that
+    # bench.py can time each kernel with its own event pair)
+    for passes, tag in ((1, "pwattn_bwd_e_bt"), (2, "pwattn_bwd_e_bh")):
+        native.call("nrm_pwattn_bwd_contract", native.ptr(dz), native.ptr(t), native.ptr(h),
+                    native.ptr(wp), 4 * D, native.ptr(dt), native.ptr(dh), native.ptr(wsp), B, T, H, D,
+                    passes, st, tag=tag)
+    _slab_reduce(wsp, nsplit, D, D, D, dw1[:, 3 * D:], 4 * D, 1)    # slabs hold dW_p^T: ws[s][d][k] -> dw1[k, 3D + d]
+    return dt, dh, dw1, db1, dw2, db2
+
+
+def _pwattn_bwd_fake(ds, t, h, w1, w2, z):
+    B, T, D = t.shape
+    H = h.shape[1]
+    f = lambda *shape: t.new_empty(shape, dtype=torch.float32)      # noqa: E731
+    return f(B, T, D), f(B, H, D), f(D, 4 * D), f(D), f(D), f(1)
+
+
+pwattn_bwd = _op("pwattn_bwd", "(Tensor ds, Tensor t, Tensor h, Tensor fc1_weight, Tensor fc2_weight, Tensor(a!) z) -> "
+                 "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)", _pwattn_bwd_impl, _pwattn_bwd_fake)
+
+
+def _pwattn_setup(ctx, inputs, output):
+    t, h, w1, b1, w2, b2, save_z = inputs
+    s, z = output
+    ctx.set_materialize_grads(False)
+    ctx.save_z = save_z
+    ctx.consumed = False
+    ctx.w2_shape, ctx.b2_shape = tuple(w2.shape), tuple(b2.shape)
+    if save_z:
+        ctx.save_for_backward(t, h, w1, w2, z)
+
+
+def _pwattn_backward(ctx, ds, _dz):
+    if ds is None:
+        return None, None, None, None, None, None, None
+    if not ctx.save_z:
+        raise RuntimeError("pointwise attention: the forward ran with save_z=False (no-grad / inference call); there "
+                           "is nothing to differentiate through")
+    if ctx.consumed:
+        # the saved pre-activation is overwritten in place by dz (2.46 GB at C3: no second copy), so the graph can be
+        # walked once; the reference's autograd would allow retain_graph=True here
+        raise RuntimeError("pointwise attention: backward through this graph a second time is not supported "
+                           "(the saved pre-activation buffer was consumed by the first backward); "
+                           "re-run the forward instead of retain_graph=True")
+    ctx.consumed = True
+    t, h, w1, w2, z = ctx.saved_tensors
+    dt, dh, dw1, db1, dw2, db2 = pwattn_bwd(ds, t, h, w1, w2, z.detach())
+    return dt, dh, dw1, db1, dw2.reshape(ctx.w2_shape), db2.reshape(ctx.b2_shape), None
+
+
+torch.library.register_autograd("nrm::pwattn_fwd", _pwattn_backward, setup_context=_pwattn_setup, lib=_LIB)
+
+
+def pointwise_attention_scores(target, history, fc1_weight, fc1_bias, fc2_weight, fc2_bias):
+    """[B,T,D] x [B,H,D] -> [B,T,H] scores (fp32).
+
+    The kernels need the feature width to be a multiple of 4 (float4 rows).  Any other D is zero-padded here with
+    differentiable ops: padded features contribute exactly 0 to every term (their fc1 rows/columns and fc2 weights
+    are 0, gelu(0) = 0), and autograd slices the gradients back."""
+    D = target.shape[-1]
+    if target.shape[0] * target.shape[1] * history.shape[1] == 0:
+        return _degenerate((target.shape[0], target.shape[1], history.shape[1]), target, history, fc1_weight, fc1_bias,
+                           fc2_weight, fc2_bias)
+    args = (target, history, fc1_weight, fc1_bias, fc2_weight, fc2_bias)
+    _require_gpu(*args)
+    # the [B,T,H,D] pre-activation is only kept when something will differentiate through the call
+    save_z = torch.is_grad_enabled() and any(a.requires_grad for a in args)
+    if D % 4:
+        P = _pad4(D) - D
+        pad = torch.nn.functional.pad
+        blocks = [pad(fc1_weight[:, i * D:(i + 1) * D], (0, P, 0, P)) for i in range(4)]     # [D4, D4] each
+        args = (pad(target.to(torch.float32), (0, P)), pad(history.to(torch.float32), (0, P)), torch.cat(blocks, dim=1),
+                pad(fc1_bias, (0, P)), pad(fc2_weight.reshape(1, D), (0, P)), fc2_bias)
+    return pwattn_fwd(*args, save_z)[0]
+
+
+# ------------------------------------------------------------------------------------------------ dense layers
+def _linear_fwd_impl(x, weight, bias, gelu):
+    _require_gpu(x, weight, bias)
+    x = _rows(x)
+    w = _f32c(weight)
+    N, K = w.shape
+    if x.shape[1] != K:
+        raise RuntimeError(f"linear: input has {x.shape[1]} features, weight expects {K}")
+    b = _f32c(bias) if bias is not None else None
+    y, z = _gemm_nt(x, w, K, 1, N, K, b, EPI_GELU if gelu else EPI_BIAS)
+    return y, (z if gelu else y.new_empty((0,)))
+
+
+def _linear_fwd_fake(x, weight, bias, gelu):
+    M, N = x.shape[0], weight.shape[0]
+    y = _padded_empty(x, M, N)
+    return y, (_padded_empty(x, M, N) if gelu else x.new_empty((0,), dtype=torch.float32))
+
+
+linear_fwd = _op("linear_fwd", "(Tensor x, Tensor weight, Tensor? bias, bool gelu) -> (Tensor, Tensor)",
+                 _linear_fwd_impl, _linear_fwd_fake)
+
+
+def _linear_bwd_impl(dy, x, weight, z, has_bias, need_dx, need_dw):
+    _require_gpu(dy, x, weight)
+    x, w = _rows(x), _f32c(weight)
+    N, K = w.shape
+    if z.numel():
+        dy = torch.ops.aten.gelu_backward(dy, z)            # exact-erf GELU' (elementwise; the fused path is mlp_gelu)
+    dy = _rows(dy)
+    dev = x.device
+    dw = db = dx = None
+    if need_dw:
+        dw, db = _gemm_tn(dy, x, has_bias)                  # dW[n,k] = sum_m dy[m,n] x[m,k]
+    if need_dx:
+        dx, _ = _gemm_nt(dy, w, 1, K, K, N, None, EPI_BIAS)  # dX = dY W : rows of the packed operand = k
+    e = lambda: torch.empty((0,), dtype=torch.float32, device=dev)      # noqa: E731
+    return (dx if dx is not None else e()), (dw if dw is not None else e()), (db if db is not None else e())
+
+
+def _linear_bwd_fake(dy, x, weight, z, has_bias, need_dx, need_dw):
+    M, (N, K) = x.shape[0], weight.shape
+    e = lambda: x.new_empty((0,), dtype=torch.float32)                  # noqa: E731
+    return (_padded_empty(x, M, K) if need_dx else e(), x.new_empty((N, K), dtype=torch.float32) if need_dw else e(),
+            x.new_empty((N,), dtype=torch.float32) if (need_dw and has_bias) else e())
+
+
+linear_bwd = _op("linear_bwd", "(Tensor dy, Tensor x, Tensor weight, Tensor z, bool has_bias, bool need_dx, bool need_dw) -> "
+                 "(Tensor, Tensor, Tensor)", _linear_bwd_impl, _linear_bwd_fake)
+
+
+def _linear_setup(ctx, inputs, output):
+    x, weight, bias, gelu = inputs
+    ctx.set_materialize_grads(False)
+    ctx.has_bias = bias is not None
+    ctx.save_for_backward(x, weight, output[1])
+
+
+def _linear_backward(ctx, dy, _dz):
+    if dy is None:
+        return None, None, None, None
+    x, weight, z = ctx.saved_tensors
+    need = ctx.needs_input_grad
+    need_dw = need[1] or (ctx.has_bias and need[2])
+    dx, dw, db = linear_bwd(dy, x, weight, z, ctx.has_bias, need[0], need_dw)
+    return (dx if need[0] else None), (dw if need[1] else None), (db if (ctx.has_bias and need[2]) else None), None
+
+
+torch.library.register_autograd("nrm::linear_fwd", _linear_backward, setup_context=_linear_setup, lib=_LIB)
 
 
 def linear(x, weight, bias=None, gelu=False):
@@ -224,106 +353,214 @@ def linear(x, weight, bias=None, gelu=False):
     lead = x.shape[:-1]
     if x.numel() == 0 and x.shape[-1] == weight.shape[1]:
         return _degenerate((*lead, weight.shape[0]), x, weight, bias)
-    y = _Linear.apply(x.reshape(-1, x.shape[-1]), weight, bias, bool(gelu))
+    _require_gpu(x, weight)
+    y = linear_fwd(x.reshape(-1, x.shape[-1]), weight, bias, bool(gelu))[0]
     return y.reshape(*lead, weight.shape[0])
 
 
-class _MlpGelu(torch.autograd.Function):
-    """fc2(gelu(fc1(x))) for a 2-D x (reference models/attention_model.py:29-32 with the default activation) as ONE
-    autograd node: forward = two GEMMs (bias + exact GELU fused into the first, its pre-activation saved); backward =
-    dW2/db2, then d(pre-activation) = (dY W2) * gelu'(z) with the GELU derivative fused into that GEMM's epilogue
-    (NRM_EPI_DGELU), then dW1/db1 and dX -- no elementwise pass over the hidden activations in either direction."""
-
-    @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
-        _require_gpu(x, w1, w2)
-        x = _rows(x)
-        w1, w2 = _f32c(w1), _f32c(w2)
-        N1, K1 = w1.shape
-        N2, K2 = w2.shape
-        if x.shape[1] != K1 or K2 != N1:
-            raise RuntimeError(f"mlp: input has {x.shape[1]} features, fc1 expects {K1}, fc2 expects {K2} hidden")
-        hidden, z = _gemm_nt(x, w1, K1, 1, N1, K1, _f32c(b1) if b1 is not None else None, 1)
-        y, _ = _gemm_nt(hidden, w2, K2, 1, N2, K2, _f32c(b2) if b2 is not None else None, 0)
-        ctx.save_for_backward(x, w1, w2, hidden, z)
-        ctx.has_bias = (b1 is not None, b2 is not None)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, w1, w2, hidden, z = ctx.saved_tensors
-        N1, K1 = w1.shape
-        N2, K2 = w2.shape
-        dy = _rows(dy)
-        need = ctx.needs_input_grad
-        dw2 = db2 = dw1 = db1 = dx = None
-        if need[3] or (ctx.has_bias[1] and need[4]):
-            dw2, db2 = _gemm_tn(dy, hidden, ctx.has_bias[1])               # dW2[n,k] = sum_m dy[m,n] hidden[m,k]
-        # d(pre-activation of fc1) = (dY W2) * gelu'(z): epilogue 2 reads z and writes the product
-        dz, _ = _gemm_nt(dy, w2, 1, K2, K2, N2, None, 2, z=z)
-        if need[1] or (ctx.has_bias[0] and need[2]):
-            dw1, db1 = _gemm_tn(dz, x, ctx.has_bias[0])
-        if need[0]:
-            dx, _ = _gemm_nt(dz, w1, 1, K1, K1, N1, None, 0)
-        return dx, dw1, (db1 if ctx.has_bias[0] else None), dw2, (db2 if ctx.has_bias[1] else None)
+def _mlp_gelu_fwd_impl(x, w1, b1, w2, b2, mul):
+    """fc2(gelu(fc1(x))) [* mul] for a 2-D x (reference models/attention_model.py:29-32 with the default activation):
+    two GEMMs, bias + exact GELU fused into the first (its pre-activation saved), bias and -- for the gate of
+    user_model.py:33 -- the product with the raw concat fused into the second."""
+    _require_gpu(x, w1, w2, mul)
+    x = _rows(x)
+    w1, w2 = _f32c(w1), _f32c(w2)
+    N1, K1 = w1.shape
+    N2, K2 = w2.shape
+    if x.shape[1] != K1 or K2 != N1:
+        raise RuntimeError(f"mlp: input has {x.shape[1]} features, fc1 expects {K1}, fc2 expects {K2} hidden")
+    hidden, z = _gemm_nt(x, w1, K1, 1, N1, K1, _f32c(b1) if b1 is not None else None, EPI_GELU)
+    if mul is None:
+        y, _ = _gemm_nt(hidden, w2, K2, 1, N2, K2, _f32c(b2) if b2 is not None else None, EPI_BIAS)
+        pre = y.new_empty((0,))
+    else:
+        m = _rows(mul)
+        if tuple(m.shape) != (x.shape[0], N2):
+            raise RuntimeError(f"mlp: multiplier {tuple(m.shape)} does not match the output {(x.shape[0], N2)}")
+        y, pre = _gemm_nt(hidden, w2, K2, 1, N2, K2, _f32c(b2) if b2 is not None else None, EPI_MUL, m=m)
+    return y, hidden, z, pre
 
 
-def mlp_gelu(x, fc1_weight, fc1_bias, fc2_weight, fc2_bias):
-    """Linear -> exact GELU -> Linear on the last dimension of x (one fused autograd node)."""
+def _mlp_gelu_fwd_fake(x, w1, b1, w2, b2, mul):
+    M, N1, N2 = x.shape[0], w1.shape[0], w2.shape[0]
+    return (_padded_empty(x, M, N2), _padded_empty(x, M, N1), _padded_empty(x, M, N1),
+            _padded_empty(x, M, N2) if mul is not None else x.new_empty((0,), dtype=torch.float32))
+
+
+mlp_gelu_fwd = _op("mlp_gelu_fwd", "(Tensor x, Tensor fc1_weight, Tensor? fc1_bias, Tensor fc2_weight, Tensor? fc2_bias, "
+                   "Tensor? mul) -> (Tensor, Tensor, Tensor, Tensor)", _mlp_gelu_fwd_impl, _mlp_gelu_fwd_fake)
+
+
+def _mlp_gelu_bwd_impl(dy, x, w1, w2, hidden, z, pre, mul, has_b1, has_b2, need_dx):
+    """dW2/db2, then d(pre-activation) = (dY W2) * gelu'(z) with the GELU derivative fused into that GEMM's epilogue
+    (NRM_EPI_DGELU), then dW1/db1 and dX -- no elementwise pass over the hidden activations in either direction.  With a
+    multiplier (the gate), dY is first split by one fused kernel into d(fc2 output) = dY * mul and d(mul) = dY * fc2 output."""
+    _require_gpu(dy, x, w1, w2)
+    x, w1, w2 = _rows(x), _f32c(w1), _f32c(w2)
+    N1, K1 = w1.shape
+    N2, K2 = w2.shape
+    dy = _rows(dy)
+    dev = x.device
+    M = x.shape[0]
+    dmul = torch.empty((0,), dtype=torch.float32, device=dev)
+    if mul is not None:
+        m = _rows(mul)
+        ld = _pad4(N2)
+        if N2 % 4 == 0:
+            dg = torch.empty(M, ld, dtype=torch.float32, device=dev)
+            dmul_buf = torch.empty(M, ld, dtype=torch.float32, device=dev)
+            native.call("nrm_mul_bwd", native.ptr(dy), dy.stride(0), native.ptr(pre), pre.stride(0), native.ptr(m), m.stride(0),
+                        native.ptr(dg), native.ptr(dmul_buf), ld, M, N2, native.stream_ptr())
+            dy, dmul = dg[:, :N2], dmul_buf[:, :N2]
+        else:
+            dy, dmul = _rows(dy * m), dy * pre
+    dw2, db2 = _gemm_tn(dy, hidden, has_b2)                          # dW2[n,k] = sum_m dy[m,n] hidden[m,k]
+    # d(pre-activation of fc1) = (dY W2) * gelu'(z): epilogue 2 reads z and writes the product
+    dz, _ = _gemm_nt(dy, w2, 1, K2, K2, N2, None, EPI_DGELU, z=z)
+    dw1, db1 = _gemm_tn(dz, x, has_b1)
+    e = lambda: torch.empty((0,), dtype=torch.float32, device=dev)      # noqa: E731
+    dx = _gemm_nt(dz, w1, 1, K1, K1, N1, None, EPI_BIAS)[0] if need_dx else e()
+    return dx, dw1, (db1 if has_b1 else e()), dw2, (db2 if has_b2 else e()), dmul
+
+
+def _mlp_gelu_bwd_fake(dy, x, w1, w2, hidden, z, pre, mul, has_b1, has_b2, need_dx):
+    M, (N1, K1), (N2, K2) = x.shape[0], w1.shape, w2.shape
+    f = lambda *shape: x.new_empty(shape, dtype=torch.float32)          # noqa: E731
+    return (_padded_empty(x, M, K1) if need_dx else f(0), f(N1, K1), f(N1) if has_b1 else f(0), f(N2, K2),
+            f(N2) if has_b2 else f(0), (_padded_empty(x, M, N2) if N2 % 4 == 0 else f(M, N2)) if mul is not None else f(0))
+
+
+mlp_gelu_bwd = _op("mlp_gelu_bwd", "(Tensor dy, Tensor x, Tensor fc1_weight, Tensor fc2_weight, Tensor hidden, Tensor z, "
+                   "Tensor pre, Tensor? mul, bool has_b1, bool has_b2, bool need_dx) -> "
+                   "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)", _mlp_gelu_bwd_impl, _mlp_gelu_bwd_fake)
+
+
+def _mlp_setup(ctx, inputs, output):
+    x, w1, b1, w2, b2, mul = inputs
+    y, hidden, z, pre = output
+    ctx.set_materialize_grads(False)
+    ctx.has_bias = (b1 is not None, b2 is not None)
+    ctx.has_mul = mul is not None
+    ctx.save_for_backward(x, w1, w2, hidden, z, pre, *((mul,) if mul is not None else ()))
+
+
+def _mlp_backward(ctx, dy, _dh, _dz, _dpre):
+    if dy is None:
+        return None, None, None, None, None, None
+    saved = ctx.saved_tensors
+    x, w1, w2, hidden, z, pre = saved[:6]
+    mul = saved[6] if ctx.has_mul else None
+    need = ctx.needs_input_grad
+    dx, dw1, db1, dw2, db2, dmul = mlp_gelu_bwd(dy, x, w1, w2, hidden, z, pre, mul, ctx.has_bias[0], ctx.has_bias[1], need[0])
+    return ((dx if need[0] else None), dw1, (db1 if ctx.has_bias[0] else None), dw2, (db2 if ctx.has_bias[1] else None),
+            (dmul if ctx.has_mul else None))
+
+
+torch.library.register_autograd("nrm::mlp_gelu_fwd", _mlp_backward, setup_context=_mlp_setup, lib=_LIB)
+
+
+def mlp_gelu(x, fc1_weight, fc1_bias, fc2_weight, fc2_bias, mul=None):
+    """Linear -> exact GELU -> Linear on the last dimension of x (one fused autograd node); ``mul`` (same shape as the
+    output) multiplies the result inside the second GEMM's epilogue."""
     lead = x.shape[:-1]
     if x.numel() == 0 and x.shape[-1] == fc1_weight.shape[1]:
-        return _degenerate((*lead, fc2_weight.shape[0]), x, fc1_weight, fc1_bias, fc2_weight, fc2_bias)
-    y = _MlpGelu.apply(x.reshape(-1, x.shape[-1]), fc1_weight, fc1_bias, fc2_weight, fc2_bias)
+        out = _degenerate((*lead, fc2_weight.shape[0]), x, fc1_weight, fc1_bias, fc2_weight, fc2_bias)
+        return out if mul is None else out * mul
+    _require_gpu(x, fc1_weight, fc2_weight)
+    m2 = mul.reshape(-1, mul.shape[-1]) if mul is not None else None
+    y = mlp_gelu_fwd(x.reshape(-1, x.shape[-1]), fc1_weight, fc1_bias, fc2_weight, fc2_bias, m2)[0]
     return y.reshape(*lead, fc2_weight.shape[0])
 
 
 # ------------------------------------------------------------------------------------------------ BatchNorm1d
-class _BatchNorm(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps):
-        _require_gpu(x, weight, bias)
-        x = _rows(x)
-        R, N = x.shape
-        ld = x.stride(0)
-        st = native.stream_ptr()
-        w, b = _f32c(weight), _f32c(bias)
-        if training:
-            s = torch.zeros(2, N, dtype=torch.float32, device=x.device)
-            native.call("nrm_colreduce", 0, native.ptr(x), None, None, None, native.ptr(s[0]), None, R, N, ld, st)
-            mean = s[0] / R
-            native.call("nrm_colreduce", 1, native.ptr(x), None, native.ptr(mean), None, native.ptr(s[1]), None, R, N, ld, st)
-            var = s[1] / R
-            with torch.no_grad():
-                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                running_var.mul_(1 - momentum).add_(var, alpha=momentum * R / max(R - 1, 1))
-        else:
-            mean, var = _f32c(running_mean), _f32c(running_var)
-        rstd = torch.rsqrt(var + eps)
-        y = torch.empty(R, ld, dtype=torch.float32, device=x.device)
-        native.call("nrm_bn_apply", native.ptr(x), native.ptr(mean), native.ptr(rstd), native.ptr(w), native.ptr(b),
-                    native.ptr(y), R, N, ld, st)
-        ctx.save_for_backward(x, mean, rstd, w)
-        ctx.training = training
-        return y[:, :N]
+def _bn_stats_impl(x, running_mean, running_var, momentum, eps):
+    """Train-mode statistics of the [R, N] rows: mean, rstd = 1/sqrt(biased var + eps) (two-pass variance), and the
+    running-statistics update of nn.BatchNorm1d (unbiased variance, momentum) in place -- two column reductions and
+    two finalisation launches, no ATen arithmetic."""
+    _require_gpu(x, running_mean, running_var)
+    x = _rows(x)
+    R, N = x.shape
+    ld = x.stride(0)
+    st = native.stream_ptr()
+    dev = x.device
+    s = torch.zeros(2, N, dtype=torch.float32, device=dev)
+    mean = torch.empty(N, dtype=torch.float32, device=dev)
+    rstd = torch.empty(N, dtype=torch.float32, device=dev)
+    native.call("nrm_colreduce", 0, native.ptr(x), None, None, None, native.ptr(s[0]), None, R, N, ld, st)
+    native.call("nrm_bn_finalize", 0, native.ptr(s[0]), native.ptr(mean), native.ptr(running_mean), R, N, float(momentum), float(eps), st)
+    native.call("nrm_colreduce", 1, native.ptr(x), None, native.ptr(mean), None, native.ptr(s[1]), None, R, N, ld, st)
+    native.call("nrm_bn_finalize", 1, native.ptr(s[1]), native.ptr(rstd), native.ptr(running_var), R, N, float(momentum), float(eps), st)
+    return mean, rstd
 
-    @staticmethod
-    def backward(ctx, dy):
-        x, mean, rstd, w = ctx.saved_tensors
-        R, N = x.shape
-        st = native.stream_ptr()
-        if not (dy.dim() == 2 and dy.stride(1) == 1 and dy.stride(0) == x.stride(0) and dy.dtype == torch.float32
-                and dy.data_ptr() % 16 == 0):
-            buf = torch.zeros(R, x.stride(0), dtype=torch.float32, device=x.device)
-            buf[:, :N] = dy
-            dy = buf[:, :N]
-        ld = x.stride(0)
-        s = torch.zeros(2, N, dtype=torch.float32, device=x.device)
-        native.call("nrm_colreduce", 2, native.ptr(x), native.ptr(dy), native.ptr(mean), native.ptr(rstd),
-                    native.ptr(s[0]), native.ptr(s[1]), R, N, ld, st)
-        dx = torch.empty(R, ld, dtype=torch.float32, device=x.device)
-        native.call("nrm_bn_backward", native.ptr(x), native.ptr(dy), native.ptr(mean), native.ptr(rstd), native.ptr(w),
-                    native.ptr(s[0]), native.ptr(s[1]), native.ptr(dx), R, N, ld, 1 if ctx.training else 0, st)
-        return dx[:, :N], s[1], s[0], None, None, None, None, None
+
+batch_norm_stats = _op("batch_norm_stats", "(Tensor x, Tensor(a!) running_mean, Tensor(b!) running_var, float momentum, float eps) -> "
+                       "(Tensor, Tensor)", _bn_stats_impl,
+                       lambda x, rm, rv, momentum, eps: (x.new_empty((x.shape[1],), dtype=torch.float32),
+                                                         x.new_empty((x.shape[1],), dtype=torch.float32)))
+
+
+def _bn_apply_impl(x, mean, rstd, weight, bias, batch_stats):
+    _require_gpu(x, mean, rstd, weight, bias)
+    x = _rows(x)
+    R, N = x.shape
+    ld = x.stride(0)
+    w, b = _f32c(weight), _f32c(bias)
+    y = torch.empty(R, ld, dtype=torch.float32, device=x.device)
+    native.call("nrm_bn_apply", native.ptr(x), native.ptr(mean), native.ptr(rstd), native.ptr(w), native.ptr(b),
+                native.ptr(y), R, N, ld, native.stream_ptr())
+    return y[:, :N]
+
+
+batch_norm_apply = _op("batch_norm_apply", "(Tensor x, Tensor mean, Tensor rstd, Tensor weight, Tensor bias, bool batch_stats) -> Tensor",
+                       _bn_apply_impl, lambda x, mean, rstd, weight, bias, batch_stats: _padded_empty(x, x.shape[0], x.shape[1]))
+
+
+def _bn_bwd_impl(dy, x, mean, rstd, weight, training):
+    _require_gpu(dy, x)
+    x = _rows(x)
+    R, N = x.shape
+    ld = x.stride(0)
+    st = native.stream_ptr()
+    dev = x.device
+    if not (dy.dim() == 2 and dy.stride(1) == 1 and dy.stride(0) == ld and dy.dtype == torch.float32
+            and dy.data_ptr() % 16 == 0):
+        buf = torch.zeros(R, ld, dtype=torch.float32, device=dev)
+        buf[:, :N] = dy
+        dy = buf[:, :N]
+    w = _f32c(weight)
+    s = torch.zeros(2, N, dtype=torch.float32, device=dev)
+    native.call("nrm_colreduce", 2, native.ptr(x), native.ptr(dy), native.ptr(mean), native.ptr(rstd),
+                native.ptr(s[0]), native.ptr(s[1]), R, N, ld, st)
+    dx = torch.empty(R, ld, dtype=torch.float32, device=dev)
+    native.call("nrm_bn_backward", native.ptr(x), native.ptr(dy), native.ptr(mean), native.ptr(rstd), native.ptr(w),
+                native.ptr(s[0]), native.ptr(s[1]), native.ptr(dx), R, N, ld, 1 if training else 0, st)
+    return dx[:, :N], s[1].clone(), s[0].clone()
+
+
+def _bn_bwd_fake(dy, x, mean, rstd, weight, training):
+    R, N = x.shape
+    return _padded_empty(x, R, N), x.new_empty((N,), dtype=torch.float32), x.new_empty((N,), dtype=torch.float32)
+
+
+batch_norm_bwd = _op("batch_norm_bwd", "(Tensor dy, Tensor x, Tensor mean, Tensor rstd, Tensor weight, bool training) -> "
+                     "(Tensor, Tensor, Tensor)", _bn_bwd_impl, _bn_bwd_fake)
+
+
+def _bn_setup(ctx, inputs, output):
+    x, mean, rstd, weight, bias, batch_stats = inputs
+    ctx.batch_stats = batch_stats
+    ctx.save_for_backward(x, mean, rstd, weight)
+
+
+def _bn_backward(ctx, dy):
+    # with batch statistics (training) mean and rstd are functions of x: their contribution is inside the dx formula of
+    # nrm_bn_backward, so no gradient is sent to the mean / rstd inputs themselves
+    x, mean, rstd, weight = ctx.saved_tensors
+    dx, dgamma, dbeta = batch_norm_bwd(dy, x, mean, rstd, weight, ctx.batch_stats)
+    return dx, None, None, dgamma, dbeta, None
+
+
+torch.library.register_autograd("nrm::batch_norm_apply", _bn_backward, setup_context=_bn_setup, lib=_LIB)
 
 
 def batch_norm(x, bn):
@@ -335,95 +572,80 @@ def batch_norm(x, bn):
     training = bn.training
     if x.shape[0] <= (1 if training else 0):
         return bn(x)          # 0/1 rows in training: nn.BatchNorm1d raises its ValueError; 0 rows in eval: empty result
+    _require_gpu(x, bn.weight)
     if training:
         bn.num_batches_tracked.add_(1)
-    return _BatchNorm.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, float(bn.momentum),
-                            float(bn.eps))
+        mean, rstd = batch_norm_stats(x.detach(), bn.running_mean, bn.running_var, float(bn.momentum), float(bn.eps))
+    else:
+        mean, rstd = bn.running_mean.to(torch.float32), torch.rsqrt(bn.running_var.to(torch.float32) + bn.eps)
+    return batch_norm_apply(x, mean, rstd, bn.weight, bn.bias, training)
 
 
 # ------------------------------------------------------------------------------------------------ pool
-class _WeightedPool(torch.autograd.Function):
+def _pool_fwd_impl(s, h):
     """pooled[b,t,:] = sum_h s[b,t,h] * h[b,h,:]  (un-normalised, unmasked: reference
     models/user_invariant_interest_model.py:86-87)."""
+    _require_gpu(s, h)
+    s, h = _f32c(s), _f32c(h)
+    B, T, H = s.shape
+    D = h.shape[2]
+    out = torch.empty(B, T, D, dtype=torch.float32, device=h.device)
+    native.call("nrm_pool_bmm", native.ptr(s), T * H, H, 1, native.ptr(h), native.ptr(out), B, T, H, D, 0,
+                native.stream_ptr())
+    return out
 
-    @staticmethod
-    def forward(ctx, s, h):
-        _require_gpu(s, h)
-        s, h = _f32c(s), _f32c(h)
-        B, T, H = s.shape
-        D = h.shape[2]
-        out = torch.empty(B, T, D, dtype=torch.float32, device=h.device)
-        native.call("nrm_pool_bmm", native.ptr(s), T * H, H, 1, native.ptr(h), native.ptr(out), B, T, H, D, 0,
-                    native.stream_ptr())
-        ctx.save_for_backward(s, h)
-        return out
 
-    @staticmethod
-    def backward(ctx, g):
-        s, h = ctx.saved_tensors
-        B, T, H = s.shape
-        D = h.shape[2]
-        g = _f32c(g)
-        st = native.stream_ptr()
-        ds = torch.empty(B, T, H, dtype=torch.float32, device=h.device)
-        native.call("nrm_pool_rowdot", native.ptr(g), native.ptr(h), native.ptr(ds), B, T, H, D, st)
-        dh = torch.empty(B, H, D, dtype=torch.float32, device=h.device)
-        native.call("nrm_pool_bmm", native.ptr(s), T * H, 1, H, native.ptr(g), native.ptr(dh), B, H, T, D, 0, st)
-        return ds, dh
+weighted_pool_fwd = _op("weighted_pool_fwd", "(Tensor scores, Tensor history) -> Tensor", _pool_fwd_impl,
+                        lambda s, h: s.new_empty((s.shape[0], s.shape[1], h.shape[2]), dtype=torch.float32))
+
+
+def _pool_bwd_impl(g, s, h):
+    _require_gpu(g, s, h)
+    s, h, g = _f32c(s), _f32c(h), _f32c(g)
+    B, T, H = s.shape
+    D = h.shape[2]
+    st = native.stream_ptr()
+    ds = torch.empty(B, T, H, dtype=torch.float32, device=h.device)
+    native.call("nrm_pool_rowdot", native.ptr(g), native.ptr(h), native.ptr(ds), B, T, H, D, st)
+    dh = torch.empty(B, H, D, dtype=torch.float32, device=h.device)
+    native.call("nrm_pool_bmm", native.ptr(s), T * H, 1, H, native.ptr(g), native.ptr(dh), B, H, T, D, 0, st)
+    return ds, dh
+
+
+weighted_pool_bwd = _op("weighted_pool_bwd", "(Tensor g, Tensor scores, Tensor history) -> (Tensor, Tensor)", _pool_bwd_impl,
+                        lambda g, s, h: (s.new_empty(tuple(s.shape), dtype=torch.float32), h.new_empty(tuple(h.shape), dtype=torch.float32)))
+
+
+def _pool_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs)
+
+
+def _pool_backward(ctx, g):
+    s, h = ctx.saved_tensors
+    return weighted_pool_bwd(g, s, h)
+
+
+torch.library.register_autograd("nrm::weighted_pool_fwd", _pool_backward, setup_context=_pool_setup, lib=_LIB)
 
 
 def weighted_pool(scores, history):
     D = history.shape[-1]
     if scores.numel() == 0:                                  # empty batch / no candidates / empty history: sum of nothing
         return _degenerate((scores.shape[0], scores.shape[1], D), scores, history)
-    if D % 4 == 0:
-        return _WeightedPool.apply(scores, history)
     _require_gpu(scores, history)
-    return _WeightedPool.apply(scores, torch.nn.functional.pad(history.to(torch.float32), (0, _pad4(D) - D)))[..., :D]
+    if D % 4 == 0:
+        return weighted_pool_fwd(scores, history)
+    return weighted_pool_fwd(scores, torch.nn.functional.pad(history.to(torch.float32), (0, _pad4(D) - D)))[..., :D]
 
 
 # ------------------------------------------------------------------------------------------------ loss
-class _SoftmaxBceLoss(torch.autograd.Function):
-    """The two-term BCE-on-softmax loss of reference models/user_model.py:37-43, value and gradients in one
-    kernel (one wave per impression)."""
-
-    @staticmethod
-    def forward(ctx, out, delta, label, user_id, alpha):
-        _require_gpu(out, delta, label, user_id)
-        B, T = out.shape
-        o = _f32c(out)
-        y = _f32c(label)
-        uid = user_id.to(torch.int64).contiguous()
-        d = _f32c(delta)
-        loss = torch.zeros(1, dtype=torch.float32, device=out.device)
-        dout = torch.empty(B, T, dtype=torch.float32, device=out.device)
-        ddelta = torch.zeros_like(d)
-        native.call("nrm_loss_fwd_bwd", native.ptr(o), native.ptr(y), native.ptr(uid), native.ptr(d), d.numel(), float(alpha),
-                    B, T, native.ptr(loss), native.ptr(dout), native.ptr(ddelta), native.ptr(index_error_flag(out.device)),
-                    native.stream_ptr())
-        ctx.save_for_backward(dout, ddelta)
-        return loss.reshape(())
-
-    @staticmethod
-    def backward(ctx, gl):
-        dout, ddelta = ctx.saved_tensors
-        return dout * gl, ddelta * gl, None, None, None
-
-
-def softmax_bce_loss(out, delta, label, user_id, alpha):
-    if out.numel() == 0:                                     # nn.BCELoss: mean over no elements
-        return _degenerate((), out, delta) + float("nan")
-    return _SoftmaxBceLoss.apply(out, delta, label, user_id, alpha)
-
-
-# ------------------------------------------------------------------------------------------------ embedding front end
 _index_error_flag = {}
 
 
 def index_error_flag(device):
-    """Device int32 set to 1 by the front-end kernel when a packed row holds an out-of-range table index (the
-    reference raises IndexError there; the kernel clamps, flags and goes on).  Reading it synchronises, so it is
-    checked by ``check_index_errors`` on request, not on every step."""
+    """Device int32 set to 1 by the front-end / loss kernels when a packed row holds an out-of-range table index or a
+    user id outside delta (the reference raises IndexError there; the kernels clamp, flag and go on).  Reading it
+    synchronises, so it is checked by ``check_index_errors`` on request, not on every step."""
     device = torch.device(device)
     if device.index is None:
         device = torch.device(device.type, torch.cuda.current_device())
@@ -437,64 +659,186 @@ def check_index_errors(device="cuda"):
     flag = index_error_flag(device)
     if int(flag.item()):
         flag.zero_()
-        raise IndexError("index out of range in a packed feature row (category / type / time table)")
+        raise IndexError("index out of range (a category / type / time table index of a packed feature row, or a user id "
+                         "outside delta)")
 
 
-class _Frontend(torch.autograd.Function):
+def _loss_impl(out, delta, label, user_id, alpha):
+    """The two-term BCE-on-softmax loss of reference models/user_model.py:37-43, value and gradients in one
+    kernel (one wave per impression)."""
+    _require_gpu(out, delta, label, user_id)
+    B, T = out.shape
+    o, y, d = _f32c(out), _f32c(label), _f32c(delta)
+    uid = user_id.to(torch.int64).contiguous()
+    loss = torch.zeros(1, dtype=torch.float32, device=out.device)
+    dout = torch.empty(B, T, dtype=torch.float32, device=out.device)
+    ddelta = torch.zeros_like(d)
+    native.call("nrm_loss_fwd_bwd", native.ptr(o), native.ptr(y), native.ptr(uid), native.ptr(d), d.numel(), float(alpha),
+                B, T, native.ptr(loss), native.ptr(dout), native.ptr(ddelta), native.ptr(index_error_flag(out.device)),
+                native.stream_ptr())
+    return loss.reshape(()), dout, ddelta
+
+
+softmax_bce_loss_op = _op("softmax_bce_loss", "(Tensor out, Tensor delta, Tensor label, Tensor user_id, float alpha) -> "
+                          "(Tensor, Tensor, Tensor)", _loss_impl,
+                          lambda out, delta, label, user_id, alpha: (out.new_empty((), dtype=torch.float32),
+                                                                     out.new_empty(tuple(out.shape), dtype=torch.float32),
+                                                                     delta.new_empty(tuple(delta.shape), dtype=torch.float32)))
+
+
+def _loss_setup(ctx, inputs, output):
+    ctx.set_materialize_grads(False)
+    ctx.save_for_backward(output[1], output[2])
+
+
+def _loss_backward(ctx, gl, _a, _b):
+    if gl is None:
+        return None, None, None, None, None
+    dout, ddelta = ctx.saved_tensors
+    return dout * gl, ddelta * gl, None, None, None
+
+
+torch.library.register_autograd("nrm::softmax_bce_loss", _loss_backward, setup_context=_loss_setup, lib=_LIB)
+
+
+def softmax_bce_loss(out, delta, label, user_id, alpha):
+    if out.numel() == 0:                                     # nn.BCELoss: mean over no elements
+        return _degenerate((), out, delta) + float("nan")
+    _require_gpu(out, delta, label, user_id)
+    return softmax_bce_loss_op(out, delta, label, user_id, float(alpha))[0]
+
+
+# ------------------------------------------------------------------------------------------------ embedding front end
+def _frontend_dims(cat_tab, sen_w, type_tab, year_tab, month_tab, day_tab, hour_tab):
+    return (cat_tab.shape[0], cat_tab.shape[1], sen_w.shape[0], type_tab.shape[0], type_tab.shape[1], year_tab.shape[0],
+            month_tab.shape[0], day_tab.shape[0], hour_tab.shape[0], year_tab.shape[1])
+
+
+def _frontend_fwd_impl(x, behaviour, n_sub, P, cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab):
     """Packed rows [R, cols] (fp32 or fp64) -> (label rows [R, e0+e1+e2+e3(+2)], text/image rows [R, P] fp32)."""
+    _require_gpu(x, cat_tab)
+    if x.dtype not in (torch.float32, torch.float64):
+        x = x.to(torch.float32)
+    x = x.contiguous()
+    R, xcols = x.shape
+    tabs = [_f32c(t) for t in (cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab)]
+    cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab = tabs
+    dims = _frontend_dims(cat_tab, sen_w, type_tab, year_tab, month_tab, day_tab, hour_tab)
+    n_cat, e0, e1, n_type, e2, n_year, n_month, n_day, n_hour, e3 = dims
+    width = e0 + e1 + e2 + e3 + (2 if behaviour else 0)
+    ldlab, ldti = _pad4(width), _pad4(P)
+    lab = torch.empty(R, ldlab, dtype=torch.float32, device=x.device)
+    ti = torch.empty(R, ldti, dtype=torch.float32, device=x.device)
+    native.call("nrm_frontend_fwd", native.ptr(x), 1 if x.dtype == torch.float64 else 0, R, xcols, P, n_sub,
+                1 if behaviour else 0, native.ptr(cat_tab), n_cat, e0, native.ptr(sen_w), native.ptr(sen_b), e1,
+                native.ptr(type_tab), n_type, e2, native.ptr(year_tab), native.ptr(month_tab), native.ptr(day_tab),
+                native.ptr(hour_tab), n_year, n_month, n_day, n_hour, e3,
+                native.ptr(lab), ldlab, native.ptr(ti), ldti, native.ptr(index_error_flag(x.device)),
+                native.stream_ptr())
+    return lab[:, :width], ti[:, :P]
 
-    @staticmethod
-    def forward(ctx, x, behaviour, n_sub, P, cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab):
-        _require_gpu(x, cat_tab)
-        if x.dtype not in (torch.float32, torch.float64):
-            x = x.to(torch.float32)
-        x = x.contiguous()
-        R, xcols = x.shape
-        tabs = [_f32c(t) for t in (cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab)]
-        cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab = tabs
-        e0, e1, e2, e3 = cat_tab.shape[1], sen_w.shape[0], type_tab.shape[1], year_tab.shape[1]
-        width = e0 + e1 + e2 + e3 + (2 if behaviour else 0)
-        ldlab, ldti = _pad4(width), _pad4(P)
-        lab = torch.empty(R, ldlab, dtype=torch.float32, device=x.device)
-        ti = torch.empty(R, ldti, dtype=torch.float32, device=x.device)
-        dims = (cat_tab.shape[0], e0, e1, type_tab.shape[0], e2, year_tab.shape[0], month_tab.shape[0],
-                day_tab.shape[0], hour_tab.shape[0], e3)
-        native.call("nrm_frontend_fwd", native.ptr(x), 1 if x.dtype == torch.float64 else 0, R, xcols, P, n_sub,
-                    1 if behaviour else 0, native.ptr(cat_tab), dims[0], e0, native.ptr(sen_w), native.ptr(sen_b), e1,
-                    native.ptr(type_tab), dims[3], e2, native.ptr(year_tab), native.ptr(month_tab), native.ptr(day_tab),
-                    native.ptr(hour_tab), dims[5], dims[6], dims[7], dims[8], e3,
-                    native.ptr(lab), ldlab, native.ptr(ti), ldti, native.ptr(index_error_flag(x.device)),
-                    native.stream_ptr())
-        ctx.save_for_backward(x, sen_w, sen_b)
-        ctx.geom = (behaviour, n_sub, P, dims)
-        ctx.mark_non_differentiable(ti)
-        return lab[:, :width], ti[:, :P]
 
-    @staticmethod
-    def backward(ctx, dlab, _dti):
-        x, sen_w, sen_b = ctx.saved_tensors
-        behaviour, n_sub, P, dims = ctx.geom
-        n_cat, e0, e1, n_type, e2, n_year, n_month, n_day, n_hour, e3 = dims
-        dlab = _rows(dlab)
-        dev = x.device
-        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
-        d_cat, d_sw, d_sb, d_type = z(n_cat, e0), z(e1, 3), z(e1), z(n_type, e2)
-        d_year, d_month, d_day, d_hour = z(n_year, e3), z(n_month, e3), z(n_day, e3), z(n_hour, e3)
-        native.call("nrm_frontend_bwd", native.ptr(x), 1 if x.dtype == torch.float64 else 0, x.shape[0], x.shape[1], P,
-                    n_sub, 1 if behaviour else 0, native.ptr(dlab), dlab.stride(0), native.ptr(sen_w), native.ptr(sen_b),
-                    n_cat, e0, e1, n_type, e2, n_year, n_month, n_day, n_hour, e3,
-                    native.ptr(d_cat), native.ptr(d_sw), native.ptr(d_sb), native.ptr(d_type),
-                    native.ptr(d_year), native.ptr(d_month), native.ptr(d_day), native.ptr(d_hour), native.stream_ptr())
-        return None, None, None, None, d_cat, d_sw, d_sb, d_type, d_year, d_month, d_day, d_hour
+def _frontend_fwd_fake(x, behaviour, n_sub, P, cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab):
+    width = cat_tab.shape[1] + sen_w.shape[0] + type_tab.shape[1] + year_tab.shape[1] + (2 if behaviour else 0)
+    return _padded_empty(x, x.shape[0], width), _padded_empty(x, x.shape[0], P)
+
+
+_FRONT_TABLES = "Tensor cat_tab, Tensor sen_w, Tensor sen_b, Tensor type_tab, Tensor year_tab, Tensor month_tab, Tensor day_tab, Tensor hour_tab"
+frontend_fwd = _op("frontend_fwd", f"(Tensor x, bool behaviour, int n_sub, int P, {_FRONT_TABLES}) -> (Tensor, Tensor)",
+                   _frontend_fwd_impl, _frontend_fwd_fake)
+
+
+def _frontend_bwd_impl(dlab, x, behaviour, n_sub, P, cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab):
+    _require_gpu(dlab, x)
+    if x.dtype not in (torch.float32, torch.float64):
+        x = x.to(torch.float32)
+    x = x.contiguous()
+    sen_w, sen_b = _f32c(sen_w), _f32c(sen_b)
+    dims = _frontend_dims(cat_tab, sen_w, type_tab, year_tab, month_tab, day_tab, hour_tab)
+    n_cat, e0, e1, n_type, e2, n_year, n_month, n_day, n_hour, e3 = dims
+    dlab = _rows(dlab)
+    dev = x.device
+    z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)      # noqa: E731
+    d_cat, d_sw, d_sb, d_type = z(n_cat, e0), z(e1, sen_w.shape[1]), z(e1), z(n_type, e2)
+    d_year, d_month, d_day, d_hour = z(n_year, e3), z(n_month, e3), z(n_day, e3), z(n_hour, e3)
+    native.call("nrm_frontend_bwd", native.ptr(x), 1 if x.dtype == torch.float64 else 0, x.shape[0], x.shape[1], P,
+                n_sub, 1 if behaviour else 0, native.ptr(dlab), dlab.stride(0), native.ptr(sen_w), native.ptr(sen_b),
+                n_cat, e0, e1, n_type, e2, n_year, n_month, n_day, n_hour, e3,
+                native.ptr(d_cat), native.ptr(d_sw), native.ptr(d_sb), native.ptr(d_type),
+                native.ptr(d_year), native.ptr(d_month), native.ptr(d_day), native.ptr(d_hour), native.stream_ptr())
+    return d_cat, d_sw, d_sb, d_type, d_year, d_month, d_day, d_hour
+
+
+def _frontend_bwd_fake(dlab, x, behaviour, n_sub, P, cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab):
+    return tuple(t.new_empty(tuple(t.shape), dtype=torch.float32)
+                 for t in (cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab))
+
+
+frontend_bwd = _op("frontend_bwd", f"(Tensor dlab, Tensor x, bool behaviour, int n_sub, int P, {_FRONT_TABLES}) -> "
+                   "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)", _frontend_bwd_impl, _frontend_bwd_fake)
+
+
+def _frontend_setup(ctx, inputs, output):
+    ctx.set_materialize_grads(False)
+    ctx.args = inputs[1:4]
+    ctx.save_for_backward(inputs[0], *inputs[4:])
+
+
+def _frontend_backward(ctx, dlab, _dti):
+    if dlab is None:
+        return (None,) * 12
+    x, *tabs = ctx.saved_tensors
+    return (None, None, None, None) + tuple(frontend_bwd(dlab, x, *ctx.args, *tabs))
+
+
+torch.library.register_autograd("nrm::frontend_fwd", _frontend_backward, setup_context=_frontend_setup, lib=_LIB)
 
 
 def frontend(x, behaviour, n_sub, P, cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab):
     """x [B, N, cols] -> (label rows [B, N, width], text/image rows [B, N, P])."""
     B, N = x.shape[0], x.shape[1]
+    tabs = (cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab)
     if B * N == 0:
-        tabs = (cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab)
         width = cat_tab.shape[1] + sen_w.shape[0] + type_tab.shape[1] + year_tab.shape[1] + (2 if behaviour else 0)
         return _degenerate((B, N, width), x, *tabs), _degenerate((B, N, int(P)), x)
-    lab, ti = _Frontend.apply(x.reshape(B * N, x.shape[2]), bool(behaviour), int(n_sub), int(P), cat_tab, sen_w, sen_b,
-                              type_tab, year_tab, month_tab, day_tab, hour_tab)
+    _require_gpu(x, cat_tab)
+    lab, ti = frontend_fwd(x.reshape(B * N, x.shape[2]), bool(behaviour), int(n_sub), int(P), *tabs)
+    ti = ti.detach()                                            # a copy of input columns: not differentiable
     return lab.reshape(B, N, -1) if lab.is_contiguous() else lab.unflatten(0, (B, N)), ti.unflatten(0, (B, N))
+
+
+# ------------------------------------------------------------------------------------------------ evaluation / optimizer
+def _row_auc_impl(score, label, length):
+    """Per-impression ROC-AUC and top-1 hit (reference train.py:77-80, verify.py:25-36)."""
+    _require_gpu(score, label, length)
+    s, y = _f32c(score), _f32c(label)
+    B, T = s.shape
+    auc = torch.empty(B, dtype=torch.float32, device=s.device)
+    top1 = torch.empty(B, dtype=torch.int32, device=s.device)
+    ln = length.to(torch.int32).contiguous() if length is not None else None
+    native.call("nrm_row_auc", native.ptr(s), native.ptr(y), native.ptr(ln) if ln is not None else None, B, T,
+                native.ptr(auc), native.ptr(top1), native.stream_ptr())
+    return auc, top1
+
+
+row_auc = _op("row_auc", "(Tensor score, Tensor label, Tensor? length) -> (Tensor, Tensor)", _row_auc_impl,
+              lambda score, label, length: (score.new_empty((score.shape[0],), dtype=torch.float32),
+                                            score.new_empty((score.shape[0],), dtype=torch.int32)))
+
+
+def _adam_step_impl(param, grad, exp_avg, exp_avg_sq, state, lr, beta1, beta2, eps, weight_decay, zero_grad):
+    """train.py:48,73-75 over one flat buffer: Adam(lr, weight_decay) + optional zero_grad in one launch; the step
+    counter lives in ``state`` on the device (hipGraph-capturable)."""
+    _require_gpu(param, grad, exp_avg, exp_avg_sq, state)
+    native.call("nrm_adam_step_dev", native.ptr(param), native.ptr(grad), native.ptr(exp_avg), native.ptr(exp_avg_sq),
+                param.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), native.ptr(state),
+                1 if zero_grad else 0, native.stream_ptr())
+
+
+adam_step = _op("adam_step", "(Tensor(a!) param, Tensor(b!) grad, Tensor(c!) exp_avg, Tensor(d!) exp_avg_sq, Tensor(e!) state, "
+                "float lr, float beta1, float beta2, float eps, float weight_decay, bool zero_grad) -> ()",
+                _adam_step_impl, lambda *a: None)
+
+OPS = ("pwattn_fwd", "pwattn_bwd", "linear_fwd", "linear_bwd", "mlp_gelu_fwd", "mlp_gelu_bwd", "batch_norm_stats", "batch_norm_apply",
+       "batch_norm_bwd",
+       "weighted_pool_fwd", "weighted_pool_bwd", "softmax_bce_loss", "frontend_fwd", "frontend_bwd", "row_auc", "adam_step")

@@ -82,11 +82,10 @@ class FlatAdam:
         return int(self.state[0].item())
 
     def step(self, zero_grad=True):
-        from . import native
-        native.call("nrm_adam_step_dev", native.ptr(self.flat_param), native.ptr(self.flat_grad),
-                    native.ptr(self.exp_avg), native.ptr(self.exp_avg_sq), self.n, float(self.param_groups[0]["lr"]),
-                    float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
-                    native.ptr(self.state), 1 if zero_grad else 0, native.stream_ptr())
+        from . import ops
+        ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.state,
+                      float(self.param_groups[0]["lr"]), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                      float(self.weight_decay), bool(zero_grad))          # torch.ops.nrm.adam_step -> nrm_adam_step_dev
 
     def zero_grad(self, set_to_none=False):
         self.flat_grad.zero_()

@@ -39,3 +39,16 @@ def test_host_validation_rejects_bad_shapes(lib):
     assert rc != 0 and b"null" in lib.nrm_last_error()
     rc = lib.nrm_pwattn_bwd_contract(None, None, None, None, 256, None, None, None, 1 << 20, 64, 64, 64, 3, None)
     assert rc != 0 and b"2^31" in lib.nrm_last_error()
+
+
+def test_torch_library_ops_are_defined_without_a_gpu():
+    """The nrm:: ops register at import time (schemas + fake functions need no device); on a CPU tensor they refuse."""
+    import pytest
+    import torch
+    from news_recommendation_model_amd import ops
+    for name in ops.OPS:
+        assert hasattr(torch.ops.nrm, name)
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.zeros(2, 4), torch.zeros(3, 4))
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        torch.ops.nrm.weighted_pool_fwd(torch.zeros(1, 2, 3), torch.zeros(1, 3, 4))

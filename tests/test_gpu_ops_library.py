@@ -1,0 +1,131 @@
+"""GPU: the hot-path operators as torch.library custom ops (namespace ``nrm``; SURVEY.md §8b "torch.library ops in one
+namespace").  Every op is reachable through ``torch.ops.nrm.*``, carries a fake-tensor shape function and an autograd
+registration that ``torch.library.opcheck`` accepts, and the Modules -- which call these ops -- still pickle into a child
+process the way reference test.py:172-182 hands its model list to a worker."""
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+# schema (incl. the mutation annotations), fake-tensor function vs real outputs, autograd registration
+CHECKS = ("test_schema", "test_faketensor", "test_autograd_registration")
+
+
+def _attn_args(B=2, T=3, H=5, D=16, grad=True):
+    g = torch.Generator(device="cuda").manual_seed(0)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)          # noqa: E731
+    t, h = r(B, T, D).requires_grad_(grad), r(B, H, D).requires_grad_(grad)
+    w1, b1 = (0.1 * r(D, 4 * D)).requires_grad_(grad), (0.1 * r(D)).requires_grad_(grad)
+    w2, b2 = r(1, D).requires_grad_(grad), r(1).requires_grad_(grad)
+    return t, h, w1, b1, w2, b2
+
+
+def test_every_op_is_registered_under_torch_ops_nrm(lib):
+    from news_recommendation_model_amd import ops
+    for name in ops.OPS:
+        packet = getattr(torch.ops.nrm, name)
+        assert packet.default._schema.name == "nrm::" + name
+    assert "Tensor(a!) z" in str(torch.ops.nrm.pwattn_bwd.default._schema)             # in-place dz is declared
+
+
+def test_opcheck_attention_and_pool(lib):
+    from news_recommendation_model_amd import ops   # noqa: F401  (registers the ops)
+    t, h, w1, b1, w2, b2 = _attn_args()
+    torch.library.opcheck(torch.ops.nrm.pwattn_fwd.default, (t, h, w1, b1, w2, b2, True), test_utils=CHECKS)
+    torch.library.opcheck(torch.ops.nrm.pwattn_fwd.default, (t.detach(), h.detach(), w1.detach(), b1.detach(), w2.detach(),
+                                                             b2.detach(), False), test_utils=CHECKS)
+    s, z = torch.ops.nrm.pwattn_fwd(t.detach(), h.detach(), w1.detach(), b1.detach(), w2.detach(), b2.detach(), True)
+    torch.library.opcheck(torch.ops.nrm.pwattn_bwd.default, (torch.randn_like(s), t.detach(), h.detach(), w1.detach(), w2.detach(), z),
+                          test_utils=CHECKS)
+    sc = torch.randn(2, 3, 5, device="cuda", requires_grad=True)
+    torch.library.opcheck(torch.ops.nrm.weighted_pool_fwd.default, (sc, h), test_utils=CHECKS)
+    torch.library.opcheck(torch.ops.nrm.weighted_pool_bwd.default, (torch.randn(2, 3, 16, device="cuda"), sc.detach(), h.detach()),
+                          test_utils=CHECKS)
+
+
+def test_opcheck_dense_batchnorm_loss_frontend(lib):
+    from news_recommendation_model_amd import config, ops, synth
+    g = torch.Generator(device="cuda").manual_seed(1)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)          # noqa: E731
+    x = r(37, 24).requires_grad_(True)
+    w, b = (0.2 * r(10, 24)).requires_grad_(True), r(10).requires_grad_(True)
+    for gelu in (False, True):
+        torch.library.opcheck(torch.ops.nrm.linear_fwd.default, (x, w, b, gelu), test_utils=CHECKS)
+    w2, b2 = (0.2 * r(24, 10)).requires_grad_(True), r(24).requires_grad_(True)
+    torch.library.opcheck(torch.ops.nrm.mlp_gelu_fwd.default, (x, w, b, w2, b2, None), test_utils=CHECKS)
+    m = r(37, 24).requires_grad_(True)
+    torch.library.opcheck(torch.ops.nrm.mlp_gelu_fwd.default, (x, w, b, w2, b2, m), test_utils=CHECKS)
+    # BatchNorm: the statistics op mutates the running buffers (declared), the apply op is functional with autograd
+    rm, rv = torch.zeros(24, device="cuda"), torch.ones(24, device="cuda")
+    torch.library.opcheck(torch.ops.nrm.batch_norm_stats.default, (x.detach(), rm, rv, 0.1, 1e-5), test_utils=CHECKS)
+    mean, rstd = torch.ops.nrm.batch_norm_stats(x.detach(), rm, rv, 0.1, 1e-5)
+    gamma, beta = r(24).requires_grad_(True), r(24).requires_grad_(True)
+    torch.library.opcheck(torch.ops.nrm.batch_norm_apply.default, (x, mean, rstd, gamma, beta, True), test_utils=CHECKS)
+    # loss
+    out = r(6, 9).requires_grad_(True)
+    delta = (0.1 * r(5)).requires_grad_(True)
+    label = torch.zeros(6, 9, device="cuda")
+    label[torch.arange(6), torch.arange(6)] = 1
+    uid = torch.tensor([0, 1, 4, 2, 2, 3], device="cuda")
+    torch.library.opcheck(torch.ops.nrm.softmax_bce_loss.default, (out, delta, label, uid, 0.95), test_utils=CHECKS)
+    # front end on packed rows
+    dims = config.Dims.for_emb(16, 40)
+    batch = synth.make_batch(dims, 3, 4, 2, seed=3, user_num=5)
+    sd = synth.make_state_dict(dims, seed=2, user_num=5)
+    inv = "invariant_interest_model."
+    tabs = [torch.from_numpy(sd[inv + k]).cuda().requires_grad_(True) for k in (
+        "category_embedding.0.weight", "sentiment_embedding.0.weight", "sentiment_embedding.0.bias", "type_embedding.0.weight",
+        "year_embedding.0.weight", "month_embedding.0.weight", "day_embedding.0.weight", "hour_embedding.0.weight")]
+    rows = torch.from_numpy(batch["x_history"]).cuda().reshape(-1, batch["x_history"].shape[-1])
+    torch.library.opcheck(torch.ops.nrm.frontend_fwd.default, (rows, True, dims.n_subcat, dims.pca_vector, *tabs), test_utils=CHECKS)
+    # evaluation + optimizer ops
+    torch.library.opcheck(torch.ops.nrm.row_auc.default, (out.detach(), label, None), test_utils=CHECKS)
+    n = 64
+    p_, g_, m_, v_ = r(n), r(n), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    st = torch.zeros(4, device="cuda")
+    torch.library.opcheck(torch.ops.nrm.adam_step.default, (p_, g_, m_, v_, st, 1e-3, 0.9, 0.999, 1e-8, 1e-5, True), test_utils=CHECKS)
+
+
+def test_ops_called_through_torch_ops_match_the_python_entry_points(lib):
+    from news_recommendation_model_amd import ops
+    t, h, w1, b1, w2, b2 = _attn_args(grad=False)
+    s_op, z = torch.ops.nrm.pwattn_fwd(t, h, w1, b1, w2, b2, False)
+    assert z.numel() == 0
+    assert torch.equal(s_op, ops.pointwise_attention_scores(t, h, w1, b1, w2, b2))
+    x = torch.randn(11, 12, device="cuda")
+    w, b = torch.randn(8, 12, device="cuda"), torch.randn(8, device="cuda")
+    y = torch.ops.nrm.linear_fwd(x, w, b, False)[0]
+    assert torch.allclose(y, torch.nn.functional.linear(x, w, b), rtol=1e-5, atol=1e-5)
+    with pytest.raises(RuntimeError):                                   # no CPU kernel exists for any nrm op
+        torch.ops.nrm.linear_fwd(x.cpu(), w.cpu(), b.cpu(), False)
+
+
+def test_modules_pickle_into_a_child_process_that_runs_the_ops(lib, tmp_path):
+    """reference test.py:172-182: the CPU-resident model list is pickled to a child Process, which moves it to the device
+    and runs it.  The child imports the package (registering the ops in ITS process) and must reproduce the parent's
+    scores."""
+    from golden_util import load_case
+    from news_recommendation_model_amd import trainer
+    case, dims, batch, sd, fx = load_case("tiny_eval")
+    model = trainer.build_model(dims, int(batch["user_num"]), sd, device="cpu").eval()
+    blob = tmp_path / "model.pkl"
+    with open(blob, "wb") as f:
+        pickle.dump({"model": model, "batch": {k: v for k, v in batch.items() if isinstance(v, np.ndarray)}}, f)
+    code = (
+        "import pickle, sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "d = pickle.load(open(%r, 'rb'))\n"
+        "m = d['model'].to('cuda').eval()\n"
+        "b = {k: torch.from_numpy(v).cuda() for k, v in d['batch'].items() if v.ndim > 0}\n"
+        "with torch.no_grad():\n"
+        "    out = m(b['x_history'], b['x_target'], b['x_global'])\n"
+        "np.save(%r, out.cpu().numpy())\n" % (str(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))),
+                                                str(blob), str(tmp_path / "out.npy")))
+    pr = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-2000:]
+    got = np.load(tmp_path / "out.npy")
+    assert np.abs(got - fx["r"]).max() / np.abs(fx["r"]).max() < 1e-3
