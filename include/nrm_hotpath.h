@@ -83,13 +83,15 @@ int nrm_gemm_tn_nsplit(int ncols_i, int ncols_j, int R);
 int nrm_gemm_tn(const float* A, int lda, int ncols_i, const float* B, int ldb, int ncols_j, int R,
                 float* ws, int ldws, float* colsum, nrm_stream_t stream);
 
-/* the split slabs ws[s][j][ldws] of nrm_gemm_tn / nrm_pwattn_bwd_contract summed over s and written where the gradient
- * lives: out[i*out_istride + j*out_jstride] = sum_s ws[s][j][i]  (i < ni, j < nj; (nj, 1) strides give C[i,j] row-major,
- * i.e. the transpose of a slab, (1, ld) a column block of a wider matrix ...).  out2 (optional) receives sign2 times the
- * same value, stored (accumulate2 == 0) or added -- the t-h block of fc1's gradient (attention_model.py:81-86) is
- * da_t - da_h.  vec [nsplit][ldws] (optional, the colsum slabs) -> vec_out[i] = sum_s vec[s][i]  (the bias gradient). */
+/* the split slabs ws[s][j][ldws] of nrm_gemm_tn / nrm_pwattn_bwd_contract summed over s and ADDED (float atomics; the
+ * caller zero-initialises, or accumulates on purpose) where the gradient lives:
+ *     out[i*out_istride + j*out_jstride] += sum_s ws[s][j][i]      (i < ni, j < nj)
+ * (nj, 1) strides give C[i,j] row-major, i.e. the transpose of a slab; (ld, 1) with an offset pointer a column block of a
+ * wider matrix.  out2 (optional) += sign2 * the same value -- the (t - h) block of fc1's gradient
+ * (attention_model.py:81-86) is da_t - da_h.  vec [nsplit][ldws] (optional, the colsum slabs of nrm_gemm_tn):
+ * vec_out[i] = sum_s vec[s][i]  (the bias gradient; stored, not added). */
 int nrm_slab_reduce(const float* ws, int nsplit, int nj, int ldws, int ni, float* out, long out_istride, long out_jstride,
-                    float* out2, long out2_istride, long out2_jstride, float sign2, int accumulate2,
+                    float* out2, long out2_istride, long out2_jstride, float sign2,
                     const float* vec, float* vec_out, nrm_stream_t stream);
 
 /* ---- BatchNorm1d over rows (reference models/user_model.py:18,32), N % 4 == 0, ld % 4 == 0.

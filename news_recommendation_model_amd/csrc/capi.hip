@@ -199,14 +199,14 @@ int nrm_gemm_tn(const float* A, int lda, int ncols_i, const float* B, int ldb, i
 }
 
 int nrm_slab_reduce(const float* ws, int nsplit, int nj, int ldws, int ni, float* out, long out_istride, long out_jstride,
-                    float* out2, long out2_istride, long out2_jstride, float sign2, int accumulate2,
+                    float* out2, long out2_istride, long out2_jstride, float sign2,
                     const float* vec, float* vec_out, nrm_stream_t stream) {
     if (!ws || !out) return fail(NRM_EINVAL, "nrm_slab_reduce: null pointer");
     if (nsplit <= 0 || nj <= 0 || ni <= 0 || ldws < ni) return fail(NRM_EINVAL, "nrm_slab_reduce: nsplit=%d nj=%d ni=%d ldws=%d", nsplit, nj, ni, ldws);
     if ((vec == nullptr) != (vec_out == nullptr)) return fail(NRM_EINVAL, "nrm_slab_reduce: vec and vec_out go together");
     nrm::SlabReduceParams p;
     p.ws = ws; p.nsplit = nsplit; p.nj = nj; p.ldws = ldws; p.ni = ni; p.out = out; p.ors = out_istride; p.ocs = out_jstride;
-    p.out2 = out2; p.ors2 = out2_istride; p.ocs2 = out2_jstride; p.sign2 = sign2; p.acc2 = accumulate2; p.vec = vec; p.vec_out = vec_out;
+    p.out2 = out2; p.ors2 = out2_istride; p.ocs2 = out2_jstride; p.sign2 = sign2; p.vec = vec; p.vec_out = vec_out;
     return check_hip(nrm::slab_reduce_launch(p, (hipStream_t)stream), "slab_reduce");
 }
 

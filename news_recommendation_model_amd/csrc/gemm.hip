@@ -357,16 +357,18 @@ hipError_t gemm_tn_launch(GemmTnParams p, const GemmTnPlan& pl, hipStream_t st) 
 // ---------------------------------------------------------------------------------------------
 // slab reduction: the partial slabs ws[s][j][i] of gemm_tn / the attention dW_p pass -> the gradient tensor itself
 // (sum over s + transpose + strided placement in ONE launch; was ATen sum(dim=0).t() + cat: 24 reduce launches and a
-// concat per step).  blockDim (32, 8); a block owns a 32(i) x 32(j) tile: reads run along i (the slab's fast index),
-// the tile is transposed through LDS and written along j.  blockIdx.y == gridDim.y - 1 sums the bias-gradient vectors.
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceParams p) {
+// concat per step).  blockDim (32, 8); a block owns a 32(i) x 32(j) tile AND a chunk of the splits (blockIdx.y), so a
+// 200 MB slab set (324 splits of 400 x 400 at C3) is streamed by thousands of blocks: reads run along i (the slab's fast
+// index), the partial tile is transposed through LDS and ADDED to the output along j with float atomics (the caller
+// zero-initialises `out`; one add per element and split chunk).  blockIdx.y == gridDim.y - 1 sums the bias vectors.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceParams p, int spc) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int nbi = (p.ni + 31) / 32;
     if (blockIdx.y == gridDim.y - 1) {                                 // vector leg (db = sum of per-split column sums)
         if (!p.vec) return;
         const int i = blockIdx.x * 256 + ty * 32 + tx;
-        if (blockIdx.x * 256 < p.ni && i < p.ni) {
+        if (i < p.ni) {
             float a = 0.f;
             for (int s = 0; s < p.nsplit; ++s) a += p.vec[(size_t)s * p.ldws + i];
             p.vec_out[i] = a;
@@ -375,28 +377,28 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceParams
     }
     if ((int)blockIdx.x >= nbi * ((p.nj + 31) / 32)) return;            // grid.x is sized for the longer of the two legs
     const int i0 = (blockIdx.x % nbi) * 32, j0 = (blockIdx.x / nbi) * 32;
+    const int s_lo = blockIdx.y * spc, s_hi = min(p.nsplit, s_lo + spc);
     const size_t slab = (size_t)p.nj * p.ldws;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    const int i = i0 + tx;
+    if (i < p.ni) {
+        for (int s = s_lo; s < s_hi; ++s) {
+            const float* src = p.ws + s * slab + (size_t)(j0 + ty) * p.ldws + i;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int j = j0 + ty + 8 * r, i = i0 + tx;
-        float a = 0.f;
-        if (i < p.ni && j < p.nj) {
-            const float* src = p.ws + (size_t)j * p.ldws + i;
-            for (int s = 0; s < p.nsplit; ++s) a += src[s * slab];
+            for (int r = 0; r < 4; ++r)
+                if (j0 + ty + 8 * r < p.nj) a[r] += src[(size_t)8 * r * p.ldws];
         }
-        tile[ty + 8 * r][tx] = a;                                      // tile[j][i]
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[ty + 8 * r][tx] = a[r];           // tile[j][i]
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int i = i0 + ty + 8 * r, j = j0 + tx;
-        if (i < p.ni && j < p.nj) {
+        const int ii = i0 + ty + 8 * r, j = j0 + tx;
+        if (ii < p.ni && j < p.nj) {
             const float v = tile[tx][ty + 8 * r];
-            p.out[i * p.ors + j * p.ocs] = v;
-            if (p.out2) {
-                float* o2 = p.out2 + i * p.ors2 + j * p.ocs2;
-                *o2 = p.acc2 ? *o2 + p.sign2 * v : p.sign2 * v;
-            }
+            atomicAdd(p.out + ii * p.ors + j * p.ocs, v);
+            if (p.out2) atomicAdd(p.out2 + ii * p.ors2 + j * p.ocs2, p.sign2 * v);
         }
     }
 }
@@ -404,9 +406,16 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceParams
 hipError_t slab_reduce_launch(const SlabReduceParams& p, hipStream_t st) {
     if (p.ni <= 0 || p.nj <= 0) return hipSuccess;
     const int nbi = (p.ni + 31) / 32, nbj = (p.nj + 31) / 32;
-    int gx = nbi * nbj;
+    const int tiles = nbi * nbj;
+    int gx = tiles;
     if (p.vec && (p.ni + 255) / 256 > gx) gx = (p.ni + 255) / 256;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx, 2), dim3(32, 8), 0, st, p);
+    int nchunk = 4096 / tiles;                                          // ~4096 blocks over the chip ...
+    if (nchunk > 32) nchunk = 32;                                       // ... but at most 32 atomic adds per output element
+    if (nchunk > (p.nsplit + 3) / 4) nchunk = (p.nsplit + 3) / 4;       // (64 x 64 gradients come in 500+ slabs) and >= 4 slabs per block
+    if (nchunk < 1) nchunk = 1;
+    const int spc = (p.nsplit + nchunk - 1) / nchunk;
+    nchunk = (p.nsplit + spc - 1) / spc;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx, nchunk + 1), dim3(32, 8), 0, st, p, spc);
     return hipGetLastError();
 }
 

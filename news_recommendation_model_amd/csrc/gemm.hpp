@@ -34,13 +34,13 @@ struct GemmTnPlan { int T, nti, ntj, nsplit, rps; };
 GemmTnPlan gemm_tn_plan(int ncols_i, int ncols_j, int R, int target_waves);
 hipError_t gemm_tn_launch(GemmTnParams p, const GemmTnPlan& pl, hipStream_t st);
 
-// out[i*ors + j*ocs] = sum_s ws[s][j][i] (i < ni, j < nj): the split slabs of gemm_tn / the dW_p pass summed and
-// written where the gradient lives (any strides: straight or transposed, or a column block of a wider matrix);
-// out2 (optional) gets sign2 * the same value, stored (acc2 == 0) or added (acc2 != 0); vec_out[i] = sum_s vec[s][i].
+// out[i*ors + j*ocs] += sum_s ws[s][j][i] (i < ni, j < nj): the split slabs of gemm_tn / the dW_p pass summed and
+// ADDED where the gradient lives (any strides: straight or transposed, or a column block of a wider matrix; float
+// atomics, the caller zero-initialises); out2 (optional) += sign2 * the same value; vec_out[i] = sum_s vec[s][i].
 struct SlabReduceParams {
     const float* ws; int nsplit, nj, ldws, ni;
     float* out; long ors, ocs;
-    float* out2; long ors2, ocs2; float sign2; int acc2;
+    float* out2; long ors2, ocs2; float sign2;
     const float* vec; float* vec_out;     // [nsplit][ldws] -> [ni], or nullptr
 };
 hipError_t slab_reduce_launch(const SlabReduceParams& p, hipStream_t st);

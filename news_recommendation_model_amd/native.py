@@ -29,7 +29,7 @@ SIGNATURES = {
     "nrm_gemm_packed_floats": (_c_l, [_c_i, _c_i]),
     "nrm_gemm_pack": (_c_i, [_c_fp, _c_l, _c_l, _c_i, _c_i, _c_fp, _c_fp]),
     "nrm_gemm_nt": (_c_i, [_c_fp, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_fp, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_i, _c_fp]),
-    "nrm_slab_reduce": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_l, _c_l, _c_fp, _c_l, _c_l, ctypes.c_float, _c_i,
+    "nrm_slab_reduce": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_l, _c_l, _c_fp, _c_l, _c_l, ctypes.c_float,
                                _c_fp, _c_fp, _c_fp]),
     "nrm_bn_finalize": (_c_i, [_c_i, _c_fp, _c_fp, _c_fp, _c_i, _c_i, ctypes.c_float, ctypes.c_float, _c_fp]),
     "nrm_mul_bwd": (_c_i, [_c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_fp]),

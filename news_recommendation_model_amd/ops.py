@@ -97,10 +97,11 @@ def _gemm_tn_slabs(a, b, want_colsum):
     return ws, cs, nsplit, ldws
 
 
-def _slab_reduce(ws, nsplit, nj, ldws, ni, out, out_is, out_js, out2=None, out2_is=0, out2_js=0, sign2=0.0, acc2=False,
+def _slab_reduce(ws, nsplit, nj, ldws, ni, out, out_is, out_js, out2=None, out2_is=0, out2_js=0, sign2=0.0,
                  vec=None, vec_out=None):
+    """out (+)= sum over the split slabs (float atomics: ``out`` / ``out2`` must be zero-initialised)."""
     native.call("nrm_slab_reduce", native.ptr(ws), nsplit, nj, ldws, ni, native.ptr(out), out_is, out_js,
-                native.ptr(out2) if out2 is not None else None, out2_is, out2_js, float(sign2), 1 if acc2 else 0,
+                native.ptr(out2) if out2 is not None else None, out2_is, out2_js, float(sign2),
                 native.ptr(vec) if vec is not None else None, native.ptr(vec_out) if vec_out is not None else None,
                 native.stream_ptr())
 
@@ -110,7 +111,7 @@ def _gemm_tn(a, b, want_colsum):
     reduce+transpose launch that writes the gradient in place (no ATen sum/t/contiguous)."""
     ni, nj = a.shape[1], b.shape[1]
     ws, cs, nsplit, ldws = _gemm_tn_slabs(a, b, want_colsum)
-    c = torch.empty(ni, nj, dtype=torch.float32, device=a.device)
+    c = torch.zeros(ni, nj, dtype=torch.float32, device=a.device)
     colsum = torch.empty(ni, dtype=torch.float32, device=a.device) if want_colsum else None
     _slab_reduce(ws, nsplit, nj, ldws, ni, c, nj, 1, vec=cs, vec_out=colsum)
     return c, colsum
@@ -189,13 +190,13 @@ def _pwattn_bwd_impl(ds, t, h, w1, w2, z):
     a_t = (w_t + w_d).contiguous()
     du2, dv2 = du.reshape(B * H, D), dv.reshape(B * T, D)
     # fc1 gradient [D, 4D] = [da_h | da_t | da_t - da_h | dW_p]: every block is written in place by a slab reduction
-    dw1 = torch.empty(D, 4 * D, dtype=torch.float32, device=dev)
+    dw1 = torch.zeros(D, 4 * D, dtype=torch.float32, device=dev)
     db1 = torch.empty(D, dtype=torch.float32, device=dev)
     ws, cs, ns, ldws = _gemm_tn_slabs(du2, h.reshape(B * H, D), True)               # du^T h, db1 = column sums of du
-    _slab_reduce(ws, ns, D, ldws, D, dw1, 4 * D, 1, out2=dw1[:, 2 * D:], out2_is=4 * D, out2_js=1, sign2=-1.0, acc2=False,
+    _slab_reduce(ws, ns, D, ldws, D, dw1, 4 * D, 1, out2=dw1[:, 2 * D:], out2_is=4 * D, out2_js=1, sign2=-1.0,
                  vec=cs, vec_out=db1)
     ws, _, ns, ldws = _gemm_tn_slabs(dv2, t.reshape(B * T, D), False)
-    _slab_reduce(ws, ns, D, ldws, D, dw1[:, D:], 4 * D, 1, out2=dw1[:, 2 * D:], out2_is=4 * D, out2_js=1, sign2=1.0, acc2=True)
+    _slab_reduce(ws, ns, D, ldws, D, dw1[:, D:], 4 * D, 1, out2=dw1[:, 2 * D:], out2_is=4 * D, out2_js=1, sign2=1.0)
     dh = _gemm_nt(du2, a_h, 1, D, D, D, None, EPI_BIAS)[0].reshape(B, H, D)        # du A_h   (D % 4 == 0: contiguous)
     dt = _gemm_nt(dv2, a_t, 1, D, D, D, None, EPI_BIAS)[0].reshape(B, T, D)        # dv A_t
     nsplit = native.load().nrm_pwattn_bwd_nsplit(B, T, H, D)

@@ -299,7 +299,8 @@ def test_hip_trajectory_follows_the_reference(lib, name):
         o = (prm.data_ptr() - opt.flat_param.data_ptr()) // 4
         m[k] = opt.exp_avg[o:o + prm.numel()].cpu().numpy()
         v[k] = opt.exp_avg_sq[o:o + prm.numel()].cpu().numpy()
-    worst = check_trajectory(fx, sd, losses, rs, rms, rvs, params, m, v, move_tol=5e-2, moment_tol=5e-2)
+    # measured on MI355X: loss 3.6e-4, logits 8e-5, BN 2e-5, parameter move 9e-5, Adam moments 5e-3 (traj_c3)
+    worst = check_trajectory(fx, sd, losses, rs, rms, rvs, params, m, v, move_tol=5e-3, moment_tol=2e-2)
     print(name, worst)
 
 
