@@ -35,6 +35,8 @@ import torch
 import torch.distributed as dist
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA (the 5 PF headline figure includes 2:1 sparsity)
+HBM_PEAK_GBS = 8000.0             # same guide: HBM3E spec peak (6.3 TB/s measured achievable)
 PMC_TRAFFIC_FILES = {"C3-large": "r2_c3_pmc_traffic.json", "C5-long": "r2_c5_pmc_traffic.json", "C2-small": "r2_c2_pmc_traffic.json"}
 
 
@@ -44,6 +46,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C3-large")
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16", "bf16x3"],
+                    help="arithmetic of the attention contractions (everything else is fp32): f32 = fp32 MFMA (default, BASELINE "
+                         "config 3); bf16x3 = bf16 MFMA on hi/lo split operands, fp32-class accuracy (default for --workload "
+                         "C2-small, BASELINE config 2); bf16 = plain bf16 operands (misses the 1e-3 parity gate on raw scores)")
     ap.add_argument("--batch", type=int, default=None, help="override per-GPU batch")
     ap.add_argument("--graph", action="store_true",
                     help="capture the step in a HIP graph and time graph replays (per-kernel event timing then "
@@ -240,11 +246,13 @@ def main():
     if args.batch:
         wl["B"] = args.batch
     B, H, T, D = wl["B"], wl["H"], wl["T"], wl["emb"]
+    if args.dtype is None:
+        args.dtype = "bf16x3" if args.workload == "C2-small" else "f32"
     dims = Dims.for_emb(D)
     user_num = 10 * B
     # same weights on every rank (seed 1), a different batch per rank (seed = rank)
     sd = synth.make_state_dict(dims, seed=1, user_num=user_num, perturb=False)
-    model = trainer.build_model(dims, user_num, sd, device=dev).train()
+    model = trainer.build_model(dims, user_num, sd, device=dev, attention_mma=args.dtype).train()
     opt = trainer.FlatAdam(model)              # Adam(lr 1e-3, wd 1e-5) + zero_grad as one launch; flat grad buffer
     reducer = None                             # the all-reduce runs on opt.flat_grad (no gather copy)
     batch = synth.make_batch(dims, B, H, T, seed=rank, user_num=user_num, dtype=np.float32)
@@ -356,6 +364,28 @@ def main():
     dom = max(heavy, key=lambda k: heavy[k]["total_ms"])
     flops_per_launch = 2.0 * B * T * H * D * D            # both attentions have width D in BASELINE shapes
     achieved = flops_per_launch / (heavy[dom]["mean_ms"] * 1e-3) / 1e12
+    peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
+    roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "flops_per_launch": flops_per_launch, "mean_launch_ms": round(heavy[dom]["mean_ms"], 4)}
+    if args.dtype != "f32":
+        # with bf16 matrix cores the contraction kernels stop being MFMA-bound: price every heavy kernel against BOTH
+        # roofs (algorithmic FLOPs vs the dense bf16 peak; algorithmic bytes = one pass over z/dz [B,T,H,D] fp32, two for the
+        # in-place dz pass, vs 8 TB/s) and report the larger fraction of the kernel with the largest summed time
+        allheavy = {k: v for k, v in kern.items() if k in HEAVY}
+        dom = max(allheavy, key=lambda k: allheavy[k]["total_ms"])
+        zbytes = 4.0 * B * T * H * D
+        bytes_per_launch = 2 * zbytes if dom == "nrm_pwattn_bwd_dz" else zbytes
+        t_s = allheavy[dom]["mean_ms"] * 1e-3
+        f_mfma = (0.0 if dom == "nrm_pwattn_bwd_dz" else flops_per_launch / t_s / 1e12 / BF16_MFMA_PEAK_TFLOPS)
+        f_hbm = bytes_per_launch / t_s / 1e9 / HBM_PEAK_GBS
+        if f_hbm >= f_mfma:
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(bytes_per_launch / t_s / 1e9, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(f_hbm, 4), "bytes_per_launch": bytes_per_launch,
+                    "mean_launch_ms": round(allheavy[dom]["mean_ms"], 4), "mfma_frac_of_bf16_peak": round(f_mfma, 4)}
+        else:
+            roof = {"bound": "mfma", "kernel": dom, "achieved": round(flops_per_launch / t_s / 1e12, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(f_mfma, 4), "flops_per_launch": flops_per_launch,
+                    "mean_launch_ms": round(allheavy[dom]["mean_ms"], 4), "hbm_frac": round(f_hbm, 4)}
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure comes from
     # the committed rocprofv3 --pmc passes of this same command (profiles/<round>_<workload>_pmc_traffic.json, written by
@@ -381,15 +411,15 @@ def main():
             "metric": "train impressions/sec", "value": round(world * B * args.steps / elapsed, 2),
             "unit": "impressions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": {"f32": "f32", "bf16": "bf16 (attention contractions: bf16 MFMA operands, fp32 accumulate; rest f32)",
+                      "bf16x3": "bf16x3 (attention contractions: bf16 MFMA on hi/lo split operands, fp32 accumulate; rest f32)"}[args.dtype],
+            "data": "synthetic",
             "config": {"workload": f"{args.workload}: EBNeRD-large-shape synthetic" if args.workload == "C3-large" else args.workload,
                        "per_gpu_batch": B, "global_batch": world * B, "hist": H, "candidates": T, "emb": D,
                        "user_num": user_num, "parallelism": f"dp{world}", "launch": "hipGraph replay" if args.graph else "eager, untimed kernels" if args.no_kernel_timing else "eager",
                        "step": "fwd+loss+bwd+allreduce+Adam(wd=1e-5)" if world > 1 else "fwd+loss+bwd+Adam(wd=1e-5)"},
             "loss": round(float(loss), 6),
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_note,
-                         "flops_per_launch": flops_per_launch, "mean_launch_ms": round(heavy[dom]["mean_ms"], 4)},
+            "roofline": dict(roof, traffic=traffic, traffic_source=traffic_note),
             "kernels": {k: {"launches": v["launches"], "mean_ms": round(v["mean_ms"], 4)} for k, v in kern.items()},
             "grad_allreduce_bytes": opt.nbytes if world > 1 else 0, "replicas_in_sync": replicas_in_sync,
             "collective": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(),

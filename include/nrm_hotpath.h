@@ -32,15 +32,26 @@ const char* nrm_last_error(void);
  * The caller supplies the two side projections of the split fc1 = [W_h | W_t | W_d | W_p]:
  *      u[b,h,:] = h[b,h,:] (W_h - W_d)^T + fc1.bias        v[b,t,:] = t[b,t,:] (W_t + W_d)^T          */
 
-/* floats to allocate for the packed copy of W_p used by nrm_pwattn_fwd */
+/* Arithmetic of the bilinear contraction, chosen per call (BASELINE config 2 names bf16, config 3 fp32):
+ *   NRM_MMA_F32   v_mfma_f32_16x16x4_f32: exact fp32 products and sums
+ *   NRM_MMA_BF16  v_mfma_f32_16x16x32_bf16: operands rounded to bf16 (the t*h product is formed in fp32 and rounded
+ *                 once, W_p / dz / h / t are rounded as they are read), fp32 accumulation starting from the fp32 u + v;
+ *                 GELU, the fc2 dot, scores, pool and every reduction stay fp32
+ *   NRM_MMA_BF16X3  the same instruction with both operands split into hi + lo bf16 parts (lo = rounding remainder) and
+ *                 three MFMAs per product (lo*hi + hi*lo + hi*hi): fp32-class accuracy (~2^-16 per product) at 3/16 of the
+ *                 fp32 MFMA time -- the arithmetic that keeps the <= 1e-3 parity gate of BASELINE with bf16 matrix cores */
+#define NRM_MMA_F32 0
+#define NRM_MMA_BF16 1
+#define NRM_MMA_BF16X3 2
+/* floats to allocate for the packed copy of W_p used by nrm_pwattn_fwd (either arithmetic) */
 long nrm_pwattn_packed_floats(int D);
-/* fc1_weight: [D, 4D] with row stride ld; packs W_p = fc1_weight[:, 3D:4D] */
-int nrm_pwattn_pack_wp(const float* fc1_weight, int ld, int D, float* packed, nrm_stream_t stream);
+/* fc1_weight: [D, 4D] with row stride ld; packs W_p = fc1_weight[:, 3D:4D] for the given arithmetic */
+int nrm_pwattn_pack_wp(const float* fc1_weight, int ld, int D, int mma, float* packed, nrm_stream_t stream);
 /* t [B,T,D], h [B,H,D], u [B,H,D], v [B,T,D] contiguous; w2 = fc2.weight [D]; b2 = fc2.bias [1];
  * z [B,T,H,D] pre-activation saved for backward (NULL in inference); s [B,T,H] scores */
 int nrm_pwattn_fwd(const float* t, const float* h, const float* u, const float* v, const float* packed_wp,
                    const float* w2, const float* b2, float* z, float* s,
-                   int B, int T, int H, int D, nrm_stream_t stream);
+                   int B, int T, int H, int D, int mma, nrm_stream_t stream);
 
 /* backward, step 1 (autograd of attention_model.py:29-32 through GELU and fc2), one pass over z:
  *   z <- dz = ds * w2 * gelu'(z) in place;  dw2[k] += sum ds*gelu(z)   (dw2 must be initialised)
@@ -58,7 +69,7 @@ int nrm_pwattn_bwd_nsplit(int B, int T, int H, int D);
  * passes: bit 0 = the (b,t)-grouped launch (dt, ws), bit 1 = the (b,h)-grouped launch (dh); 3 = both. */
 int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, const float* wp, int ldwp,
                             float* dt, float* dh, float* ws,
-                            int B, int T, int H, int D, int passes, nrm_stream_t stream);
+                            int B, int T, int H, int D, int passes, int mma, nrm_stream_t stream);
 
 /* ---- dense layers: reference MLP.forward (models/attention_model.py:29-32: fc1 -> GELU -> fc2), the history
  *      projection w1 (models/user_invariant_interest_model.py:78) and the attention's side projections.

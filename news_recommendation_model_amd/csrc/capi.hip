@@ -54,20 +54,29 @@ const char* nrm_last_error(void) { return g_err; }
 long nrm_pwattn_packed_floats(int D) {
     if (D <= 0) return 0;
     const nrm::FwdPlan pl = nrm::pwattn_fwd_plan(D);
-    return (long)pl.kchunks * pl.rows * 16 + 256 * 4 * 2;   // + over-read pad of the staging loop
+    // fp32: kchunks 16-column chunks of rows x 64 B; bf16x3: two images per 32-column chunk (an odd chunk count rounds up)
+    return (long)(pl.kchunks + 1) / 2 * 2 * pl.rows * 16 + 256 * 4 * 2;   // + over-read pad of the staging loop
 }
 
-int nrm_pwattn_pack_wp(const float* fc1_weight, int ld, int D, float* packed, nrm_stream_t stream) {
+static int check_mma(const char* fn, int mma) {
+    if (mma != NRM_MMA_F32 && mma != NRM_MMA_BF16 && mma != NRM_MMA_BF16X3)
+        return fail(NRM_EINVAL, "%s: mma=%d (NRM_MMA_F32, NRM_MMA_BF16 or NRM_MMA_BF16X3)", fn, mma);
+    return NRM_OK;
+}
+
+int nrm_pwattn_pack_wp(const float* fc1_weight, int ld, int D, int mma, float* packed, nrm_stream_t stream) {
     if (!fc1_weight || !packed) return fail(NRM_EINVAL, "nrm_pwattn_pack_wp: null pointer");
     if (D <= 0 || D % 4 || ld < 4 * D) return fail(NRM_EINVAL, "nrm_pwattn_pack_wp: D=%d ld=%d (need D%%4==0, ld>=4D)", D, ld);
+    if (int rc = check_mma("nrm_pwattn_pack_wp", mma)) return rc;
     const nrm::FwdPlan pl = nrm::pwattn_fwd_plan(D);
-    return check_hip(nrm::pack_wp_launch(fc1_weight + 3 * (long)D, ld, D, pl, packed, (hipStream_t)stream), "pack_wp");
+    return check_hip(nrm::pack_wp_launch(fc1_weight + 3 * (long)D, ld, D, pl, mma, packed, (hipStream_t)stream), "pack_wp");
 }
 
 int nrm_pwattn_fwd(const float* t, const float* h, const float* u, const float* v, const float* packed_wp,
                    const float* w2, const float* b2, float* z, float* s,
-                   int B, int T, int H, int D, nrm_stream_t stream) {
+                   int B, int T, int H, int D, int mma, nrm_stream_t stream) {
     if (int rc = check_dims("nrm_pwattn_fwd", B, T, H, D)) return rc;
+    if (int rc = check_mma("nrm_pwattn_fwd", mma)) return rc;
     if (!t || !h || !u || !v || !packed_wp || !w2 || !b2 || !s) return fail(NRM_EINVAL, "nrm_pwattn_fwd: null pointer");
     if (B == 0) return NRM_OK;
     const nrm::FwdPlan pl = nrm::pwattn_fwd_plan(D);
@@ -78,8 +87,8 @@ int nrm_pwattn_fwd(const float* t, const float* h, const float* u, const float* 
     p.wp_bytes = (unsigned)(nrm_pwattn_packed_floats(D) * 4);
     p.t_bytes = (unsigned)((long)B * T * D * 4);
     p.h_bytes = (unsigned)((long)B * H * D * 4);
-    p.rows = pl.rows; p.kchunks = pl.kchunks; p.nchunks = pl.nchunks;
-    return check_hip(nrm::pwattn_fwd_launch(p, pl, (hipStream_t)stream), "pwattn_fwd");
+    p.rows = pl.rows; p.kchunks = mma != NRM_MMA_F32 ? (pl.kchunks + 1) / 2 : pl.kchunks; p.nchunks = pl.nchunks;
+    return check_hip(nrm::pwattn_fwd_launch(p, pl, mma, (hipStream_t)stream), "pwattn_fwd");
 }
 
 int nrm_pwattn_bwd_dz(float* z_inout, const float* ds, const float* w2, float* dw2, float* du, float* dv,
@@ -98,8 +107,11 @@ int nrm_pwattn_bwd_nsplit(int B, int T, int H, int D) {
 }
 
 int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, const float* wp, int ldwp,
-                            float* dt, float* dh, float* ws, int B, int T, int H, int D, int passes, nrm_stream_t stream) {
+                            float* dt, float* dh, float* ws, int B, int T, int H, int D, int passes, int mma,
+                            nrm_stream_t stream) {
     if (int rc = check_dims("nrm_pwattn_bwd_contract", B, T, H, D)) return rc;
+    if (int rc = check_mma("nrm_pwattn_bwd_contract", mma)) return rc;
+
     if (!dz || !t || !h || !wp) return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: null pointer");
     if (passes < 1 || passes > 3) return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: passes=%d", passes);
     if (((passes & 1) && (!dt || !ws)) || ((passes & 2) && !dh)) return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: null output");
@@ -116,7 +128,7 @@ int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, con
         int tw1 = kBtWaves;
         if (const char* e = getenv("NRM_BT_WAVES")) tw1 = atoi(e);
         const nrm::BwdEPlan pl = nrm::bwd_e_plan(D, p.G, tw1);
-        if (int rc = check_hip(nrm::bwd_e_launch(p, pl, true, (hipStream_t)stream), "bwd_e pass 1")) return rc;
+        if (int rc = check_hip(nrm::bwd_e_launch(p, pl, true, mma, (hipStream_t)stream), "bwd_e pass 1")) return rc;
     }
     // pass 2: groups (b,h); rows r = t.  X_g = dz[b,:,h,:], Y_g = t[b];  out = dh
     if (passes & 2) {
@@ -129,7 +141,7 @@ int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, con
         int tw = kBhWaves;
         if (const char* e = getenv("NRM_BH_WAVES")) tw = atoi(e);
         const nrm::BwdEPlan pl = nrm::bwd_e_plan(D, p.G, tw);
-        if (int rc = check_hip(nrm::bwd_e_launch(p, pl, false, (hipStream_t)stream), "bwd_e pass 2")) return rc;
+        if (int rc = check_hip(nrm::bwd_e_launch(p, pl, false, mma, (hipStream_t)stream), "bwd_e pass 2")) return rc;
     }
     return NRM_OK;
 }

@@ -8,6 +8,7 @@ namespace nrm {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;       // one v_mfma_f32_16x16x32_bf16 operand (4 VGPRs)
 
 constexpr int WAVE = 64;
 

@@ -20,13 +20,13 @@ struct FwdParams {
     int ldt, ldh, ldu, ldv;
     unsigned wp_bytes, t_bytes, h_bytes;   // buffer-descriptor extents (t/v share t_bytes, h/u share h_bytes)
     int rows;            // padded row count of packed W_p  (= nchunks * NT * 16)
-    int kchunks;         // ceil(D/16)
+    int kchunks;         // K-chunks of the packed W_p: ceil(D/16) (fp32 operands) or ceil(D/32) (bf16 operands)
     int nchunks;         // number of N-chunks (each NT*16 output columns)
 };
 struct FwdPlan { int NT, MT, nchunks, rows, kchunks; };
 FwdPlan pwattn_fwd_plan(int D);
-hipError_t pwattn_fwd_launch(const FwdParams& p, const FwdPlan& pl, hipStream_t st);
-hipError_t pack_wp_launch(const float* w, int ldw, int D, const FwdPlan& pl, float* packed, hipStream_t st);
+hipError_t pwattn_fwd_launch(const FwdParams& p, const FwdPlan& pl, int mma, hipStream_t st);
+hipError_t pack_wp_launch(const float* w, int ldw, int D, const FwdPlan& pl, int mma, float* packed, hipStream_t st);
 
 // ---- backward (pwattn_bwd.hip)
 struct BwdEParams {
@@ -43,7 +43,7 @@ struct BwdEParams {
 };
 struct BwdEPlan { int DT, KT, ndcol, nkw, nsplit, gps; };
 BwdEPlan bwd_e_plan(int D, int G, int target_waves);
-hipError_t bwd_e_launch(const BwdEParams& p, const BwdEPlan& pl, bool with_dw, hipStream_t st);
+hipError_t bwd_e_launch(const BwdEParams& p, const BwdEPlan& pl, bool with_dw, int mma, hipStream_t st);
 hipError_t bwd_dz_launch(float* z, const float* ds, const float* w2, float* dw2, float* du, float* dv,
                          int B, int T, int H, int D, hipStream_t st);
 

@@ -19,6 +19,9 @@
 #define NRM_PIPE_SGB 1
 #endif
 // timing diagnostics only (scripts/_diag/build_diag.sh): results are WRONG with any of them set
+#ifndef NRM_EPI_AHEAD
+#define NRM_EPI_AHEAD 1       // dt/dW pass: W_p^T LDS reads two tiles ahead in the epilogue (0: one read, one wait, per tile)
+#endif
 #ifndef NRM_DIAG_NOEPI
 #define NRM_DIAG_NOEPI 0      // contraction kernels without the per-group epilogue
 #endif
@@ -196,10 +199,17 @@ hipError_t bwd_dz_launch(float* z, const float* ds, const float* w2, float* dw2,
 __device__ __forceinline__ int tile_col(int tile, int row) { return tile < 4 ? 4 * row + tile : 64 + row; }
 __device__ __forceinline__ int tile_pos(int c) { return c < 64 ? 16 * (c & 3) + (c >> 2) : c; }
 
-template <int KT, int DT, int KS, bool WITH_DW, bool EXACT>
-__global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
+// BF16 (NRM_MMA_BF16): the same grouped contraction on v_mfma_f32_16x16x32_bf16.  Operands are read exactly as in the fp32
+// form (fp32 rows, the same lane -> column map); eight 4-row reduction steps are rounded to bf16 and packed into ONE
+// 32-deep MFMA operand per tile -- reduction position (lane quarter q, element j) is row 32*ss + 4*j + q for BOTH operands, which
+// is all a dot product needs.  Accumulators (E and dW_p), the epilogue and every reduction stay fp32.
+// MMA == 2 (NRM_MMA_BF16X3): both operands are split hi + lo (lo = the bf16 rounding remainder) and every product takes three
+// MFMAs (lo*hi + hi*lo + hi*hi): fp32-class accuracy at 3/16 of the fp32 MFMA time.
+template <int KT, int DT, int KS, bool WITH_DW, bool EXACT, int MMA = 0>
+__global__ __launch_bounds__(256, (MMA && KT > 4) || (MMA == 2 && WITH_DW) ? 1 : 2) void bwd_e_kernel(const BwdEParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-descriptor builtins: device pass only (keeps the host stub)
     static_assert(KS == DT, "one pass over the whole d range per group (the 3+2 sub-pass split is gone)");
+    constexpr bool BF16 = MMA != 0;
     constexpr int LDK = KT * 16 + 8;      // padded row of the W_p^T tile: +8 is conflict-free under gfx950 b128 lane groups (+4 is 2-way)
     __shared__ __attribute__((aligned(16))) float smem[DT * 16 * LDK + 4 * DT * 16];
     float* wpt = smem;                                                  // [DT*16 d][LDK]  = W_p[k0+k][d0+d]
@@ -308,6 +318,40 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
             if (DT > 4) sr[4] = srow[(EXACT || d0 + 64 + r16 < D) ? d0 + 64 + r16 : 0];
         }
         f32x4 E[KT][DT];
+        if (BF16) {
+            const int nss = (R + 31) >> 5;
+            for (int ss = 0; ss < nss; ++ss) {
+                bf16x8 af[KT], bf[DT], al[KT], bl[DT];
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) {
+                    load_step(a0, b0, 8 * ss + 2 * jp);
+                    load_step(a1, b1, 8 * ss + 2 * jp + 1);
+#pragma unroll
+                    for (int it = 0; it < KT; ++it) {
+                        af[it][2 * jp] = (__bf16)a0[it]; af[it][2 * jp + 1] = (__bf16)a1[it];
+                        if (MMA == 2) { al[it][2 * jp] = (__bf16)(a0[it] - (float)af[it][2 * jp]); al[it][2 * jp + 1] = (__bf16)(a1[it] - (float)af[it][2 * jp + 1]); }
+                    }
+#pragma unroll
+                    for (int jt = 0; jt < DT; ++jt) {
+                        bf[jt][2 * jp] = (__bf16)b0[jt]; bf[jt][2 * jp + 1] = (__bf16)b1[jt];
+                        if (MMA == 2) { bl[jt][2 * jp] = (__bf16)(b0[jt] - (float)bf[jt][2 * jp]); bl[jt][2 * jp + 1] = (__bf16)(b1[jt] - (float)bf[jt][2 * jp + 1]); }
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < KT; ++it)
+#pragma unroll
+                    for (int jt = 0; jt < DT; ++jt) {
+                        f32x4 c = E[it][jt];
+                        if (ss == 0) c = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (MMA == 2) {
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[it], bf[jt], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[it], bl[jt], c, 0, 0, 0);
+                        }
+                        E[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[it], bf[jt], c, 0, 0, 0);
+                    }
+            }
+            if (gn < g_hi) open_group(gn);
+        }
         auto mfma_batch = [&](const float (&a)[KT], const float (&b)[DT]) {
 #pragma unroll
             for (int it = 0; it < 4; ++it)                              // fed by the two 16-byte loads
@@ -318,6 +362,7 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
 #pragma unroll
                 for (int jt = (it < 4 ? 4 : 0); jt < DT; ++jt) E[it][jt] = mfma16(a[it], b[jt], E[it][jt]);
         };
+        if (!BF16) {
         // step 0 accumulates onto an inline-constant 0 (no accumulator clearing)
 #pragma unroll
         for (int it = 0; it < 4; ++it)
@@ -343,7 +388,11 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
         if (gn < g_hi) {
             open_group(gn);
             load_step(a0, b0, 0);
-            if (nsteps > 1) load_step(a1, b1, 1);
+            // WITH_DW: step 1 of the next group is requested AFTER the epilogue arithmetic (still before this group's float
+            // atomics, which vmcnt would otherwise put in front of it): operand set 1 is dead during the epilogue, and
+            // those registers let the W_p^T reads run two tiles ahead of their FMAs instead of being waited one by one
+            if (!(WITH_DW && NRM_EPI_AHEAD) && nsteps > 1) load_step(a1, b1, 1);
+        }
         }
 
         // epilogue: lane holds E[k = k0 + tile_col(it, 4q+e)][d = d0 + tile_col(jt, r16)]; the LDS image of W_p^T is
@@ -355,6 +404,29 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
 #pragma unroll
                 for (int jt = 0; jt < DT; ++jt) keep += E[it][jt][0];
             if (keep == 123.456f) bounce[r16] = keep;
+            return;
+        }
+        if (WITH_DW && NRM_EPI_AHEAD && !BF16) {
+            // flattened (jt, it) order, LDS reads two tiles ahead of their FMAs
+            constexpr int NTILE = KT * DT;
+            auto rd = [&](int n) { return *reinterpret_cast<const f32x4*>(&wpt[(16 * (n / KT) + r16) * LDK + 16 * (n % KT) + 4 * q]); };
+            f32x4 wa = rd(0), wb = rd(1), wc;
+            float acc = 0.f;
+#pragma unroll
+            for (int n = 0; n < NTILE; ++n) {
+                const int jt = n / KT, it = n % KT;
+                if (n + 2 < NTILE) wc = rd(n + 2);
+                const f32x4 e4 = E[it][jt];
+                acc = fmaf(wa[0], e4[0], fmaf(wa[1], e4[1], fmaf(wa[2], e4[2], fmaf(wa[3], e4[3], acc))));
+                dW[it][jt] += e4 * sr[jt];
+                if (it == KT - 1) {
+                    acc = sum_rows4(acc);
+                    if (q == 0) bounce[tile_col(jt, r16)] = acc;
+                    acc = 0.f;
+                }
+                wa = wb; wb = wc;
+            }
+            if (gn < g_hi && nsteps > 1) load_step(a1, b1, 1);
             return;
         }
 #pragma unroll
@@ -386,8 +458,10 @@ __global__ __launch_bounds__(256, 2) void bwd_e_kernel(const BwdEParams p) {
 
     if (g_lo < g_hi) {
         open_group(g_lo);
-        load_step(a0, b0, 0);
-        if (nsteps > 1) load_step(a1, b1, 1);
+        if (!BF16) {
+            load_step(a0, b0, 0);
+            if (nsteps > 1) load_step(a1, b1, 1);
+        }
     }
     diag_first = false;
     for (int g = g_lo; g < g_hi; ++g) {
@@ -648,11 +722,24 @@ static bool pipe_enabled() {
 }
 
 template <int KT, int DT>
-static hipError_t launch_e_t(BwdEParams p, const BwdEPlan& pl, bool with_dw, hipStream_t st) {
+static hipError_t launch_e_t(BwdEParams p, const BwdEPlan& pl, bool with_dw, int mma, hipStream_t st) {
     p.nkw = pl.nkw; p.ndcol = pl.ndcol; p.gps = pl.gps; p.nsplit = pl.nsplit;
     const dim3 grid(pl.nkw * pl.ndcol, (pl.nsplit + 3) / 4), block(256);
     const bool exact = p.D % (16 * KT) == 0 && p.D % (16 * DT) == 0;
     constexpr int KS_DW = DT;     // single pass (40 B of scratch at 5x5); the 3+2 sub-pass split is KS_DW = (DT + 1) / 2
+    if (mma == 1 || mma == 2) {
+#define NRM_LAUNCH_E(M)                                                                                              \
+        if (with_dw) {                                                                                               \
+            if (exact) hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, true, M>), grid, block, 0, st, p);       \
+            else       hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, false, M>), grid, block, 0, st, p);      \
+        } else {                                                                                                     \
+            if (exact) hipLaunchKernelGGL((bwd_e_kernel<KT, DT, DT, false, true, M>), grid, block, 0, st, p);         \
+            else       hipLaunchKernelGGL((bwd_e_kernel<KT, DT, DT, false, false, M>), grid, block, 0, st, p);        \
+        }
+        if (mma == 1) { NRM_LAUNCH_E(1) } else { NRM_LAUNCH_E(2) }
+#undef NRM_LAUNCH_E
+        return hipGetLastError();
+    }
     if (with_dw) {
         if (exact) hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, true>), grid, block, 0, st, p);
         else       hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, false>), grid, block, 0, st, p);
@@ -666,10 +753,10 @@ static hipError_t launch_e_t(BwdEParams p, const BwdEPlan& pl, bool with_dw, hip
     return hipGetLastError();
 }
 
-hipError_t bwd_e_launch(const BwdEParams& p, const BwdEPlan& pl, bool with_dw, hipStream_t st) {
+hipError_t bwd_e_launch(const BwdEParams& p, const BwdEPlan& pl, bool with_dw, int mma, hipStream_t st) {
     if (p.G <= 0) return hipSuccess;
-    if (pl.DT == 5) return launch_e_t<5, 5>(p, pl, with_dw, st);
-    return launch_e_t<4, 4>(p, pl, with_dw, st);
+    if (pl.DT == 5) return launch_e_t<5, 5>(p, pl, with_dw, mma, st);
+    return launch_e_t<4, 4>(p, pl, with_dw, mma, st);
 }
 
 }  // namespace nrm

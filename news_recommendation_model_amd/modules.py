@@ -54,15 +54,17 @@ class MLP(nn.Module):
         return y if mul is None else y * mul
 
 
-def _scores(mlp: MLP, target, history):
+def _scores(mlp: MLP, target, history, mma=None):
     if not isinstance(mlp.activation, nn.GELU):
         raise RuntimeError("the HIP attention kernel implements the reference default (exact GELU) only")
     return ops.pointwise_attention_scores(target, history, mlp.fc1.weight, mlp.fc1.bias,
-                                          mlp.fc2.weight, mlp.fc2.bias)
+                                          mlp.fc2.weight, mlp.fc2.bias, mma=mma)
 
 
 class PointwiseAttentionExpanded(nn.Module):
     """score[b,t,h] = MLP(cat[h, t, t-h, t*h]) for every (candidate, history) pair -> [B,T,H,1]."""
+
+    mma = None          # arithmetic of the contraction: None = ops.set_attention_arithmetic default, 'f32' or 'bf16'
 
     def __init__(self, input_dim):
         super().__init__()
@@ -71,7 +73,7 @@ class PointwiseAttentionExpanded(nn.Module):
     def forward(self, target, history):
         if target.dim() == 2:                      # a single target per impression
             target = target.unsqueeze(1)
-        return _scores(self.mlp, target, history).unsqueeze(-1)
+        return _scores(self.mlp, target, history, self.mma).unsqueeze(-1)
 
 
 class PointwiseAttention(nn.Module):

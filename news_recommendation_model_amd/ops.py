@@ -17,6 +17,30 @@ import torch
 from . import native
 
 EPI_BIAS, EPI_GELU, EPI_DGELU, EPI_MUL = 0, 1, 2, 3
+MMA_F32, MMA_BF16, MMA_BF16X3 = 0, 1, 2     # NRM_MMA_* of include/nrm_hotpath.h: arithmetic of the attention's bilinear contraction
+_MMA_NAMES = {"f32": MMA_F32, "fp32": MMA_F32, "float32": MMA_F32, "bf16": MMA_BF16, "bfloat16": MMA_BF16, "bf16x3": MMA_BF16X3}
+_default_mma = MMA_F32
+
+
+def resolve_mma(mma):
+    """'f32' | 'bf16' | 'bf16x3' | NRM_MMA_* | None (= the process-wide default set by ``set_attention_arithmetic``)."""
+    if mma is None:
+        return _default_mma
+    if isinstance(mma, str):
+        if mma.lower() not in _MMA_NAMES:
+            raise ValueError(f"attention arithmetic {mma!r}: expected 'f32', 'bf16' or 'bf16x3'")
+        return _MMA_NAMES[mma.lower()]
+    if int(mma) not in (MMA_F32, MMA_BF16, MMA_BF16X3):
+        raise ValueError(f"attention arithmetic {mma!r}: expected NRM_MMA_F32 (0), NRM_MMA_BF16 (1) or NRM_MMA_BF16X3 (2)")
+    return int(mma)
+
+
+def set_attention_arithmetic(mma):
+    """Process-wide default for attentions that do not carry their own ``mma`` attribute: 'f32' (BASELINE config 3,
+    the default), 'bf16' (bf16 MFMA operands, fp32 accumulation) or 'bf16x3' (bf16 MFMA with hi/lo split operands:
+    fp32-class accuracy -- the arithmetic BASELINE config 2 is run with)."""
+    global _default_mma
+    _default_mma = resolve_mma(mma)
 
 
 def _require_gpu(*tensors):
@@ -129,7 +153,7 @@ def _op(name, schema, impl, fake):
 
 
 # ------------------------------------------------------------------------------------------------ pointwise attention
-def _pwattn_fwd_impl(t, h, w1, b1, w2, b2, save_z):
+def _pwattn_fwd_impl(t, h, w1, b1, w2, b2, save_z, mma):
     """s[b,t,h] = fc2(GELU(fc1(cat[h, t, t-h, t*h]))) with fc1 = [W_h|W_t|W_d|W_p] re-associated as
     z = h(W_h-W_d)^T + b1 + t(W_t+W_d)^T + sum_d W_p[:,d] t_d h_d  (SURVEY.md §8 a7)."""
     _require_gpu(t, h, w1, b1, w2, b2)
@@ -147,16 +171,16 @@ def _pwattn_fwd_impl(t, h, w1, b1, w2, b2, save_z):
     v, _ = _gemm_nt(t.reshape(B * T, D), a_t, D, 1, D, D, None, EPI_BIAS)     # [B*T, D]
     st = native.stream_ptr()
     packed = torch.empty(native.load().nrm_pwattn_packed_floats(D), dtype=torch.float32, device=t.device)
-    native.call("nrm_pwattn_pack_wp", native.ptr(w1), 4 * D, D, native.ptr(packed), st)
+    native.call("nrm_pwattn_pack_wp", native.ptr(w1), 4 * D, D, mma, native.ptr(packed), st)
     s = torch.empty(B, T, H, dtype=torch.float32, device=t.device)
     z = torch.empty((B, T, H, D) if save_z else (0,), dtype=torch.float32, device=t.device)
     native.call("nrm_pwattn_fwd", native.ptr(t), native.ptr(h), native.ptr(u), native.ptr(v),
                 native.ptr(packed), native.ptr(w2v), native.ptr(b2),
-                native.ptr(z) if save_z else None, native.ptr(s), B, T, H, D, st)
+                native.ptr(z) if save_z else None, native.ptr(s), B, T, H, D, mma, st)
     return s, z
 
 
-def _pwattn_fwd_fake(t, h, w1, b1, w2, b2, save_z):
+def _pwattn_fwd_fake(t, h, w1, b1, w2, b2, save_z, mma):
     B, T, D = t.shape
     H = h.shape[1]
     return (t.new_empty((B, T, H), dtype=torch.float32),
@@ -164,10 +188,10 @@ def _pwattn_fwd_fake(t, h, w1, b1, w2, b2, save_z):
 
 
 pwattn_fwd = _op("pwattn_fwd", "(Tensor t, Tensor h, Tensor fc1_weight, Tensor fc1_bias, Tensor fc2_weight, Tensor fc2_bias, "
-                 "bool save_z) -> (Tensor, Tensor)", _pwattn_fwd_impl, _pwattn_fwd_fake)
+                 "bool save_z, int mma) -> (Tensor, Tensor)", _pwattn_fwd_impl, _pwattn_fwd_fake)
 
 
-def _pwattn_bwd_impl(ds, t, h, w1, w2, z):
+def _pwattn_bwd_impl(ds, t, h, w1, w2, z, mma):
     """All gradients of one attention from ds [B,T,H] and the saved pre-activation z [B,T,H,D], which is overwritten
     in place by dz (schema: Tensor(a!))."""
     _require_gpu(ds, t, h, w1, w2, z)
@@ -207,27 +231,28 @@ def _pwattn_bwd_impl(ds, t, h, w1, w2, z):
     for passes, tag in ((1, "pwattn_bwd_e_bt"), (2, "pwattn_bwd_e_bh")):
         native.call("nrm_pwattn_bwd_contract", native.ptr(dz), native.ptr(t), native.ptr(h),
                     native.ptr(wp), 4 * D, native.ptr(dt), native.ptr(dh), native.ptr(wsp), B, T, H, D,
-                    passes, st, tag=tag)
+                    passes, mma, st, tag=tag)
     _slab_reduce(wsp, nsplit, D, D, D, dw1[:, 3 * D:], 4 * D, 1)    # slabs hold dW_p^T: ws[s][d][k] -> dw1[k, 3D + d]
     return dt, dh, dw1, db1, dw2, db2
 
 
-def _pwattn_bwd_fake(ds, t, h, w1, w2, z):
+def _pwattn_bwd_fake(ds, t, h, w1, w2, z, mma):
     B, T, D = t.shape
     H = h.shape[1]
     f = lambda *shape: t.new_empty(shape, dtype=torch.float32)      # noqa: E731
     return f(B, T, D), f(B, H, D), f(D, 4 * D), f(D), f(D), f(1)
 
 
-pwattn_bwd = _op("pwattn_bwd", "(Tensor ds, Tensor t, Tensor h, Tensor fc1_weight, Tensor fc2_weight, Tensor(a!) z) -> "
+pwattn_bwd = _op("pwattn_bwd", "(Tensor ds, Tensor t, Tensor h, Tensor fc1_weight, Tensor fc2_weight, Tensor(a!) z, int mma) -> "
                  "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)", _pwattn_bwd_impl, _pwattn_bwd_fake)
 
 
 def _pwattn_setup(ctx, inputs, output):
-    t, h, w1, b1, w2, b2, save_z = inputs
+    t, h, w1, b1, w2, b2, save_z, mma = inputs
     s, z = output
     ctx.set_materialize_grads(False)
     ctx.save_z = save_z
+    ctx.mma = mma
     ctx.consumed = False
     ctx.w2_shape, ctx.b2_shape = tuple(w2.shape), tuple(b2.shape)
     if save_z:
@@ -236,7 +261,7 @@ def _pwattn_setup(ctx, inputs, output):
 
 def _pwattn_backward(ctx, ds, _dz):
     if ds is None:
-        return None, None, None, None, None, None, None
+        return None, None, None, None, None, None, None, None
     if not ctx.save_z:
         raise RuntimeError("pointwise attention: the forward ran with save_z=False (no-grad / inference call); there "
                            "is nothing to differentiate through")
@@ -248,15 +273,16 @@ def _pwattn_backward(ctx, ds, _dz):
                            "re-run the forward instead of retain_graph=True")
     ctx.consumed = True
     t, h, w1, w2, z = ctx.saved_tensors
-    dt, dh, dw1, db1, dw2, db2 = pwattn_bwd(ds, t, h, w1, w2, z.detach())
-    return dt, dh, dw1, db1, dw2.reshape(ctx.w2_shape), db2.reshape(ctx.b2_shape), None
+    dt, dh, dw1, db1, dw2, db2 = pwattn_bwd(ds, t, h, w1, w2, z.detach(), ctx.mma)
+    return dt, dh, dw1, db1, dw2.reshape(ctx.w2_shape), db2.reshape(ctx.b2_shape), None, None
 
 
 torch.library.register_autograd("nrm::pwattn_fwd", _pwattn_backward, setup_context=_pwattn_setup, lib=_LIB)
 
 
-def pointwise_attention_scores(target, history, fc1_weight, fc1_bias, fc2_weight, fc2_bias):
-    """[B,T,D] x [B,H,D] -> [B,T,H] scores (fp32).
+def pointwise_attention_scores(target, history, fc1_weight, fc1_bias, fc2_weight, fc2_bias, mma=None):
+    """[B,T,D] x [B,H,D] -> [B,T,H] scores (fp32).  ``mma``: arithmetic of the bilinear contraction ('f32' | 'bf16' |
+    None = process default); the side projections, GELU, fc2 and all reductions are fp32 either way.
 
     The kernels need the feature width to be a multiple of 4 (float4 rows).  Any other D is zero-padded here with
     differentiable ops: padded features contribute exactly 0 to every term (their fc1 rows/columns and fc2 weights
@@ -275,7 +301,7 @@ def pointwise_attention_scores(target, history, fc1_weight, fc1_bias, fc2_weight
         blocks = [pad(fc1_weight[:, i * D:(i + 1) * D], (0, P, 0, P)) for i in range(4)]     # [D4, D4] each
         args = (pad(target.to(torch.float32), (0, P)), pad(history.to(torch.float32), (0, P)), torch.cat(blocks, dim=1),
                 pad(fc1_bias, (0, P)), pad(fc2_weight.reshape(1, D), (0, P)), fc2_bias)
-    return pwattn_fwd(*args, save_z)[0]
+    return pwattn_fwd(*args, save_z, resolve_mma(mma))[0]
 
 
 # ------------------------------------------------------------------------------------------------ dense layers

@@ -16,9 +16,10 @@ import torch.distributed as dist
 from .config import Dims, model_config
 
 
-def build_model(dims: Dims, user_num: int, state_dict=None, device="cuda"):
+def build_model(dims: Dims, user_num: int, state_dict=None, device="cuda", attention_mma=None):
     """Construct a UserModel with the given dims (re-dimensions ``model_config`` the way the
-    reference is re-dimensioned: dims are read at construction)."""
+    reference is re-dimensioned: dims are read at construction).  ``attention_mma`` ('f32' | 'bf16') pins the
+    arithmetic of both attentions' contraction on this model (None: the process default, fp32)."""
     from .modules import UserInvariantInterestModel, UserModel
     saved = dict(model_config)
     saved_defaults = UserInvariantInterestModel.__init__.__defaults__
@@ -32,6 +33,11 @@ def build_model(dims: Dims, user_num: int, state_dict=None, device="cuda"):
         UserInvariantInterestModel.__init__.__defaults__ = saved_defaults
     if state_dict is not None:
         model.load_state_dict({k: torch.as_tensor(v) for k, v in state_dict.items()}, strict=False)
+    if attention_mma is not None:
+        from . import ops
+        ops.resolve_mma(attention_mma)                        # validates the name
+        model.invariant_interest_model.label_attention.mma = attention_mma
+        model.invariant_interest_model.text_img_attention.mma = attention_mma
     return model.to(device)
 
 

@@ -33,12 +33,14 @@ def test_abi_version_and_sizes(lib):
 
 def test_host_validation_rejects_bad_shapes(lib):
     # null pointers / bad D are refused on the host before any launch
-    rc = lib.nrm_pwattn_fwd(None, None, None, None, None, None, None, None, None, 2, 3, 4, 66, None)
+    rc = lib.nrm_pwattn_fwd(None, None, None, None, None, None, None, None, None, 2, 3, 4, 66, 0, None)
     assert rc != 0 and b"multiple of 4" in lib.nrm_last_error()
-    rc = lib.nrm_pwattn_fwd(None, None, None, None, None, None, None, None, None, 2, 3, 4, 64, None)
+    rc = lib.nrm_pwattn_fwd(None, None, None, None, None, None, None, None, None, 2, 3, 4, 64, 0, None)
     assert rc != 0 and b"null" in lib.nrm_last_error()
-    rc = lib.nrm_pwattn_bwd_contract(None, None, None, None, 256, None, None, None, 1 << 20, 64, 64, 64, 3, None)
+    rc = lib.nrm_pwattn_bwd_contract(None, None, None, None, 256, None, None, None, 1 << 20, 64, 64, 64, 3, 0, None)
     assert rc != 0 and b"2^31" in lib.nrm_last_error()
+    rc = lib.nrm_pwattn_fwd(None, None, None, None, None, None, None, None, None, 2, 3, 4, 64, 7, None)
+    assert rc != 0 and b"mma" in lib.nrm_last_error()          # unknown arithmetic selector
 
 
 def test_torch_library_ops_are_defined_without_a_gpu():

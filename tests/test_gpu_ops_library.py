@@ -35,11 +35,11 @@ def test_every_op_is_registered_under_torch_ops_nrm(lib):
 def test_opcheck_attention_and_pool(lib):
     from news_recommendation_model_amd import ops   # noqa: F401  (registers the ops)
     t, h, w1, b1, w2, b2 = _attn_args()
-    torch.library.opcheck(torch.ops.nrm.pwattn_fwd.default, (t, h, w1, b1, w2, b2, True), test_utils=CHECKS)
+    torch.library.opcheck(torch.ops.nrm.pwattn_fwd.default, (t, h, w1, b1, w2, b2, True, 0), test_utils=CHECKS)
     torch.library.opcheck(torch.ops.nrm.pwattn_fwd.default, (t.detach(), h.detach(), w1.detach(), b1.detach(), w2.detach(),
-                                                             b2.detach(), False), test_utils=CHECKS)
-    s, z = torch.ops.nrm.pwattn_fwd(t.detach(), h.detach(), w1.detach(), b1.detach(), w2.detach(), b2.detach(), True)
-    torch.library.opcheck(torch.ops.nrm.pwattn_bwd.default, (torch.randn_like(s), t.detach(), h.detach(), w1.detach(), w2.detach(), z),
+                                                             b2.detach(), False, 1), test_utils=CHECKS)
+    s, z = torch.ops.nrm.pwattn_fwd(t.detach(), h.detach(), w1.detach(), b1.detach(), w2.detach(), b2.detach(), True, 0)
+    torch.library.opcheck(torch.ops.nrm.pwattn_bwd.default, (torch.randn_like(s), t.detach(), h.detach(), w1.detach(), w2.detach(), z, 0),
                           test_utils=CHECKS)
     sc = torch.randn(2, 3, 5, device="cuda", requires_grad=True)
     torch.library.opcheck(torch.ops.nrm.weighted_pool_fwd.default, (sc, h), test_utils=CHECKS)
@@ -93,7 +93,7 @@ def test_opcheck_dense_batchnorm_loss_frontend(lib):
 def test_ops_called_through_torch_ops_match_the_python_entry_points(lib):
     from news_recommendation_model_amd import ops
     t, h, w1, b1, w2, b2 = _attn_args(grad=False)
-    s_op, z = torch.ops.nrm.pwattn_fwd(t, h, w1, b1, w2, b2, False)
+    s_op, z = torch.ops.nrm.pwattn_fwd(t, h, w1, b1, w2, b2, False, 0)
     assert z.numel() == 0
     assert torch.equal(s_op, ops.pointwise_attention_scores(t, h, w1, b1, w2, b2))
     x = torch.randn(11, 12, device="cuda")
