@@ -48,53 +48,14 @@ __global__ void pack_wp_kernel(const float* __restrict__ w, int ldw, int D, int 
     }
 }
 
-// bf16 MFMA operand form (NRM_MMA_BF16): packed[c][row][32 bf16] = W_p[row][32c .. 32c+31] rounded to bf16, again 64-B rows
-// with XOR-swizzled 16-B slots.  Slot s holds the 8 reduction positions a lane quarter s feeds to v_mfma_f32_16x16x32_bf16:
-// columns 32c + 4s + {0..3} and 32c + 16 + 4s + {0..3} -- the order in which the kernel reads t*h from its two 16-column
-// fp32 images (any order works for a dot product as long as both operands use the same one).
-// NRM_MMA_BF16X3 (nimg = 2): every K-chunk is followed by a second image of the rounding remainders
-// lo = bf16(w - float(bf16(w))): hi*hi + lo*hi + hi*lo reproduces the fp32 product to ~2^-16.
-__global__ void pack_wp_bf16_kernel(const float* __restrict__ w, int ldw, int D, int rows, int kchunks32, int nimg,
-                                    __bf16* __restrict__ packed) {
-    const long per_chunk = (long)rows * 32;
-    const long total = (long)kchunks32 * per_chunk;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int j = (int)(i & 31);
-        const long rc = i >> 5;
-        const int row = (int)(rc % rows);
-        const int c = (int)(rc / rows);
-        const int slot = (j >> 3) ^ swz4(row);
-        const int e = j & 7;
-        const int d = c * 32 + 16 * (e >> 2) + 4 * slot + (e & 3);
-        const float v = (row < D && d < D) ? w[(long)row * ldw + d] : 0.0f;
-        const __bf16 hi = (__bf16)v;
-        const long o = (long)c * nimg * per_chunk + (long)row * 32 + j;
-        packed[o] = hi;
-        if (nimg > 1) packed[o + per_chunk] = (__bf16)(v - (float)hi);
-    }
-}
-
-// waves per SIMD the LDS image allows (one 4-wave workgroup = one wave per SIMD), capped at the register target WPE
-constexpr int fwd_waves(int NT, int MT, int WPE, int MMA) {
-    const int lds = 2 * ((MMA == 2 ? 2 : 1) * NT * 16 + 2 * (MMA ? 2 : 1) * 4 * MT * 16) * 16 * 4;
-    const int fit = 160 * 1024 / lds;
-    return fit < 1 ? 1 : (fit < WPE ? fit : WPE);
-}
-
-// MMA: 0 = fp32 MFMA, 1 = bf16 operands, 2 = bf16x3 (hi/lo split of both operands, three MFMAs per product)
-template <int NT, int MT, bool SAVE_Z, int WPE = 2, int MMA = 0>
-__global__ __launch_bounds__(256, fwd_waves(NT, MT, WPE, MMA)) void pwattn_fwd_kernel(const FwdParams p) {
+template <int NT, int MT, bool SAVE_Z, int WPE = 2>
+__global__ __launch_bounds__(256, WPE) void pwattn_fwd_kernel(const FwdParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-descriptor types/builtins exist in the device pass only;
                                          // without the guard the host pass silently drops the kernel stub
     constexpr int BM = 4 * MT * 16;       // data rows per workgroup
-    constexpr bool BF16 = MMA != 0;
-    constexpr int WIMG = MMA == 2 ? 2 : 1;                             // W images per K-chunk (hi [, lo])
     constexpr int WROWS = NT * 16;
-    // one LDS buffer = [W chunk | t rows | h rows], every row 16 floats (64 B), unpadded (LDS-DMA image).
-    // BF16: a K-chunk is 32 columns: the W rows hold 32 bf16 (still 64 B) and t / h come as TWO 16-column fp32 images
-    constexpr int XIMG = BF16 ? 2 : 1;
-    constexpr int WL = WIMG * WROWS;                                   // LDS rows of the W part
-    constexpr int BUF = (WL + 2 * XIMG * BM) * 16;
+    // one LDS buffer = [W chunk | t rows | h rows], every row 16 floats (64 B), unpadded (LDS-DMA image)
+    constexpr int BUF = (WROWS + 2 * BM) * 16;
     __shared__ __attribute__((aligned(16))) float smem[2 * BUF];       // double buffered
 
     const int tid = threadIdx.x;
@@ -187,64 +148,19 @@ __global__ __launch_bounds__(256, fwd_waves(NT, MT, WPE, MMA)) void pwattn_fwd_k
         // K-chunk c of this N-chunk -> LDS buffer `buf` (asynchronous; completion is tracked by vmcnt).
         // Columns >= D of the last chunk need no mask: the packed W_p is zero there.
         auto dma_chunk = [&](int c, float* buf) {
+            const int wbase = (c * p.rows + nc * WROWS) * 64;             // bytes, uniform
+            for (int pc = wave; pc < NT; pc += 4)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(buf + pc * 256),
+                                                         16, lane * 16, wbase + pc * 1024, 0, 0);
 #pragma unroll
-            for (int im = 0; im < WIMG; ++im) {
-                const int wbase = ((c * WIMG + im) * p.rows + nc * WROWS) * 64;     // bytes, uniform
-                for (int pc = wave; pc < NT; pc += 4)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(buf + (im * NT + pc) * 256),
-                                                             16, lane * 16, wbase + pc * 1024, 0, 0);
-            }
-#pragma unroll
-            for (int x = 0; x < XIMG; ++x)
-#pragma unroll
-                for (int j = 0; j < MT; ++j) {
-                    float* tdst = buf + (WL + 2 * x * BM + (wave * MT + j) * 16) * 16;
-                    const int cb = (XIMG * c + x) * 64;                   // byte offset of the 16-column fp32 chunk in a row
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_t, (__attribute__((address_space(3))) void*)tdst, 16, voff_t[j], cb, 0, 0);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (__attribute__((address_space(3))) void*)(tdst + BM * 16), 16, voff_h[j], cb, 0, 0);
-                }
-        };
-        // bf16 operands: the t*h product is formed in fp32 and rounded once; W_p was rounded by the pack kernel;
-        // accumulation (starting from the fp32 u + v) stays fp32
-        auto compute_bf16 = [&](const float* buf) {
-            const float* Tl = buf + WL * 16;
-            bf16x8 pf[MT], pl[MT];
-#pragma unroll
-            for (int jt = 0; jt < MT; ++jt) {
-                const int ro = ((wave * MT + jt) * 16 + r16) * 16 + rslot;
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(&Tl[ro]) * *reinterpret_cast<const f32x4*>(&Tl[BM * 16 + ro]);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(&Tl[2 * BM * 16 + ro]) * *reinterpret_cast<const f32x4*>(&Tl[3 * BM * 16 + ro]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    pf[jt][e] = (__bf16)lo[e]; pf[jt][4 + e] = (__bf16)hi[e];
-                    if (MMA == 2) { pl[jt][e] = (__bf16)(lo[e] - (float)pf[jt][e]); pl[jt][4 + e] = (__bf16)(hi[e] - (float)pf[jt][4 + e]); }
-                }
-            }
-            bf16x8 af = *reinterpret_cast<const bf16x8*>(&buf[r16 * 16 + rslot]), al = af;
-            if (MMA == 2) al = *reinterpret_cast<const bf16x8*>(&buf[(WROWS + r16) * 16 + rslot]);
-#pragma unroll
-            for (int it = 0; it < NT; ++it) {
-                bf16x8 afn = af, aln = al;
-                if (it + 1 < NT) {
-                    afn = *reinterpret_cast<const bf16x8*>(&buf[((it + 1) * 16 + r16) * 16 + rslot]);
-                    if (MMA == 2) aln = *reinterpret_cast<const bf16x8*>(&buf[(WROWS + (it + 1) * 16 + r16) * 16 + rslot]);
-                }
-                if (WPE < 3 || it < nt_live)
-#pragma unroll
-                    for (int jt = 0; jt < MT; ++jt) {
-                        if (MMA == 2) {                                // small terms first
-                            acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, pf[jt], acc[it][jt], 0, 0, 0);
-                            acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pl[jt], acc[it][jt], 0, 0, 0);
-                        }
-                        acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pf[jt], acc[it][jt], 0, 0, 0);
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-                af = afn; al = aln;
+            for (int j = 0; j < MT; ++j) {
+                float* tdst = buf + (WROWS + (wave * MT + j) * 16) * 16;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_t, (__attribute__((address_space(3))) void*)tdst, 16, voff_t[j], c * 64, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (__attribute__((address_space(3))) void*)(tdst + BM * 16), 16, voff_h[j], c * 64, 0, 0);
             }
         };
-
         auto compute = [&](const float* buf) {
-            const float* Tl = buf + WL * 16;
+            const float* Tl = buf + WROWS * 16;
             f32x4 pf[MT];                                    // B operand rows: P[m,:] = t[b,t,:] * h[b,h,:]
 #pragma unroll
             for (int jt = 0; jt < MT; ++jt) {
@@ -276,7 +192,7 @@ __global__ __launch_bounds__(256, fwd_waves(NT, MT, WPE, MMA)) void pwattn_fwd_k
             float* cur = smem + (c & 1) * BUF;
             float* nxt = smem + ((c & 1) ^ 1) * BUF;
             if (c + 1 < p.kchunks && !((NRM_DIAG_FWD & 2) && c > 0)) dma_chunk(c + 1, nxt);
-            if (BF16) compute_bf16(cur); else compute(cur);
+            compute(cur);
             __syncthreads();
         }
 
@@ -340,47 +256,38 @@ FwdPlan pwattn_fwd_plan(int D) {
 }
 
 template <int NT, int MT, int WPE = 2>
-static hipError_t launch_fwd_t(const FwdParams& p, int mma, hipStream_t st) {
+static hipError_t launch_fwd_t(const FwdParams& p, hipStream_t st) {
     constexpr int BM = 4 * MT * 16;
     const long nblk = (p.M + BM - 1) / BM;
     if (nblk <= 0) return hipSuccess;
     if (nblk > 0x7fffffffL) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)nblk), block(256);
-    if (mma == 1) {
-        if (p.z) hipLaunchKernelGGL((pwattn_fwd_kernel<NT, MT, true, WPE, 1>), grid, block, 0, st, p);
-        else     hipLaunchKernelGGL((pwattn_fwd_kernel<NT, MT, false, WPE, 1>), grid, block, 0, st, p);
-    } else if (mma == 2) {
-        if (p.z) hipLaunchKernelGGL((pwattn_fwd_kernel<NT, MT, true, WPE, 2>), grid, block, 0, st, p);
-        else     hipLaunchKernelGGL((pwattn_fwd_kernel<NT, MT, false, WPE, 2>), grid, block, 0, st, p);
-    } else {
-        if (p.z) hipLaunchKernelGGL((pwattn_fwd_kernel<NT, MT, true, WPE>), grid, block, 0, st, p);
-        else     hipLaunchKernelGGL((pwattn_fwd_kernel<NT, MT, false, WPE>), grid, block, 0, st, p);
-    }
+    if (p.z) hipLaunchKernelGGL((pwattn_fwd_kernel<NT, MT, true, WPE>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+    else     hipLaunchKernelGGL((pwattn_fwd_kernel<NT, MT, false, WPE>), dim3((unsigned)nblk), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 
 hipError_t pwattn_fwd_launch(const FwdParams& p, const FwdPlan& pl, int mma, hipStream_t st) {
+    if (mma) return pwattn_fwd_bf16_launch(p, mma, st);
     switch (pl.NT) {
-        case 4:  return launch_fwd_t<4, 4>(p, mma, st);
-        case 6:  return launch_fwd_t<6, 4>(p, mma, st);
-        case 8:  return launch_fwd_t<8, 3>(p, mma, st);
-        case 10: return launch_fwd_t<10, 1, 3>(p, mma, st);
-        case 12: return launch_fwd_t<12, 1, 3>(p, mma, st);
-        case 13: return launch_fwd_t<13, 1, 3>(p, mma, st);
-        case 14: return launch_fwd_t<14, 2>(p, mma, st);
-        case 16: return launch_fwd_t<16, 1>(p, mma, st);
-        case 20: return launch_fwd_t<20, 1>(p, mma, st);
-        case 25: return launch_fwd_t<25, 1>(p, mma, st);
+        case 4:  return launch_fwd_t<4, 4>(p, st);
+        case 6:  return launch_fwd_t<6, 4>(p, st);
+        case 8:  return launch_fwd_t<8, 3>(p, st);
+        case 10: return launch_fwd_t<10, 1, 3>(p, st);
+        case 12: return launch_fwd_t<12, 1, 3>(p, st);
+        case 13: return launch_fwd_t<13, 1, 3>(p, st);
+        case 14: return launch_fwd_t<14, 2>(p, st);
+        case 16: return launch_fwd_t<16, 1>(p, st);
+        case 20: return launch_fwd_t<20, 1>(p, st);
+        case 25: return launch_fwd_t<25, 1>(p, st);
     }
     return hipErrorInvalidValue;
 }
 
 hipError_t pack_wp_launch(const float* w, int ldw, int D, const FwdPlan& pl, int mma, float* packed, hipStream_t st) {
-    const long total = (long)pl.kchunks * pl.rows * 16;                 // elements: fp32 in 16-column chunks, bf16 in 32-column chunks
+    if (mma) return pack_wp_bf16_launch(w, ldw, D, mma, packed, st);
+    const long total = (long)pl.kchunks * pl.rows * 16;
     const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-    if (mma) hipLaunchKernelGGL(pack_wp_bf16_kernel, dim3(blocks), dim3(256), 0, st, w, ldw, D, pl.rows, (pl.kchunks + 1) / 2,
-                                mma == 2 ? 2 : 1, reinterpret_cast<__bf16*>(packed));
-    else      hipLaunchKernelGGL(pack_wp_kernel, dim3(blocks), dim3(256), 0, st, w, ldw, D, pl.rows, pl.kchunks, packed);
+    hipLaunchKernelGGL(pack_wp_kernel, dim3(blocks), dim3(256), 0, st, w, ldw, D, pl.rows, pl.kchunks, packed);
     return hipGetLastError();
 }
 

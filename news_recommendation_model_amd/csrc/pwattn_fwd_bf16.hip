@@ -1,0 +1,271 @@
+// Pointwise history attention, forward, bf16 matrix cores (NRM_MMA_BF16 / NRM_MMA_BF16X3).  gfx950 / MI355X only.
+//
+// Same mathematics and the same MFMA orientation as pwattn_fwd.hip (rows m = (b,t,h) are MFMA columns, a lane ends up with
+// 4 consecutive k of one row; accumulators start at the fp32 u + v; epilogue = z store, exact GELU, fc2 dot), but built
+// around what changes when the contraction runs 16x (bf16) or 16/3x (bf16x3) faster than on the fp32 matrix pipe: one
+// K-chunk of MFMA work (a few hundred cycles) is far shorter than the latency of the LDS-DMA that would bring the next W_p
+// chunk, and a workgroup barrier per chunk then parks every wave of the CU on it (measured on the chunk-streaming forms:
+// 41 % of wave cycles in s_waitcnt / s_barrier, 31 % in issue stalls, matrix pipe 16 % busy).  So here W_p does not
+// stream at all:
+//   * RESIDENT W_p: the output columns k are cut into `nsplit` slices whose bf16 image (hi [, lo]; all reduction chunks)
+//     fits the 160 KB of LDS; a PERSISTENT workgroup loads its slice once and then walks row tiles, so the steady state
+//     has no LDS-DMA, no barrier, no shared state: its 8 waves run independently, one 16-row tile at a time each;
+//   * t and h do not pass through LDS either: lane (r16, q) reads the 8 + 8 floats of ITS row that its MFMA operand needs
+//     straight into registers (two 16-byte loads each, one chunk ahead), forms t*h in fp32 and rounds once (bf16) or
+//     splits it into hi + lo (bf16x3);
+//   * with more than one slice every slice adds its partial fc2 dot to s[m] (float atomic; two addends commute exactly).
+// timing diagnostics only (scripts/_diag/build_diag.sh): results are WRONG with any bit set
+#ifndef NRM_DIAG_RW
+#define NRM_DIAG_RW 0         // bit 0: no z store, bit 1: no GELU (plain sum), bit 2: t/h loaded once per tile (chunk 0 re-used),
+#endif                        // bit 3: no u+v accumulator-init loads
+#include "common.hpp"
+#include "pwattn.hpp"
+
+namespace nrm {
+
+constexpr int FB_WAVES = 16;      // waves per persistent workgroup: 4 per SIMD, <= 128 VGPRs each
+
+// W_p prepack for the bf16 MFMA: packed[c][img][row][32 bf16] = W_p[row][32c .. 32c+31] rounded to bf16 (img 0) and, for
+// bf16x3, the rounding remainders lo = bf16(w - float(hi)) (img 1): hi*hi + lo*hi + hi*lo reproduces the fp32 product to
+// ~2^-16.  64-B rows with XOR-swizzled 16-B slots as in the fp32 image (pwattn_fwd.hip); slot s holds the 8 reduction
+// positions lane quarter s feeds to v_mfma_f32_16x16x32_bf16: columns 32c + 4s + {0..3} and 32c + 16 + 4s + {0..3} -- the order
+// in which the kernel holds its two 16-byte t / h loads (any order works for a dot product as long as both operands agree).
+__global__ void pack_wp_bf16_kernel(const float* __restrict__ w, int ldw, int D, int rows, int kchunks32, int nimg,
+                                    __bf16* __restrict__ packed) {
+    const long per_chunk = (long)rows * 32;
+    const long total = (long)kchunks32 * per_chunk;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 31);
+        const long rc = i >> 5;
+        const int row = (int)(rc % rows);
+        const int c = (int)(rc / rows);
+        const int slot = (j >> 3) ^ swz4(row);
+        const int e = j & 7;
+        const int d = c * 32 + 16 * (e >> 2) + 4 * slot + (e & 3);
+        const float v = (row < D && d < D) ? w[(long)row * ldw + d] : 0.0f;
+        const __bf16 hi = (__bf16)v;
+        const long o = (long)c * nimg * per_chunk + (long)row * 32 + j;
+        packed[o] = hi;
+        if (nimg > 1) packed[o + per_chunk] = (__bf16)(v - (float)hi);
+    }
+}
+
+hipError_t pack_wp_bf16_launch(const float* w, int ldw, int D, int mma, float* packed, hipStream_t st) {
+    const RwPlan pl = pwattn_rw_plan(D, mma);
+    if (pl.nts == 0) return hipErrorInvalidValue;
+    const long total = (long)pl.k32 * pl.rows * 32;
+    const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_wp_bf16_kernel, dim3(blocks), dim3(256), 0, st, w, ldw, D, pl.rows, pl.k32, pl.wimg,
+                       reinterpret_cast<__bf16*>(packed));
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// resident-W plan: NTS 16-column tiles of output columns per slice, nsplit slices
+static const int kRwNts[7] = {1, 2, 3, 4, 5, 6, 8};      // <= 8 tiles: 32 accumulator VGPRs, the kernel stays under 128 (4 waves/SIMD)
+constexpr int RW_LDS_BUDGET = 156 * 1024;
+
+RwPlan pwattn_rw_plan(int D, int mma) {
+    RwPlan pl;
+    const int n16 = (D + 15) / 16;
+    pl.k32 = (D + 31) / 32;
+    pl.wimg = mma == 2 ? 2 : 1;
+    const int tile_bytes = pl.k32 * pl.wimg * 1024;                    // one 16-column tile, all chunks and images
+    int fit = RW_LDS_BUDGET / tile_bytes;
+    if (fit < 1) { pl.nts = 0; pl.nsplit = 0; pl.rows = 0; return pl; }     // D > 2496 (bf16) / 1248 (bf16x3): not supported
+    if (fit > 8) fit = 8;
+    int nsplit = (n16 + fit - 1) / fit;
+    for (;; ++nsplit) {
+        const int need = (n16 + nsplit - 1) / nsplit;
+        int nts = 0;
+        for (int i = 0; i < 7; ++i) if (kRwNts[i] >= need) { nts = kRwNts[i]; break; }
+        if (nts && nts <= fit) { pl.nts = nts; break; }
+    }
+    pl.nsplit = nsplit;
+    pl.rows = pl.nsplit * pl.nts * 16;
+    return pl;
+}
+
+// packed[c][img][row][32 bf16] (pack_wp_bf16_kernel) with rows = plan.rows
+template <int NTS, bool SAVE_Z, int MMA>
+__global__ __launch_bounds__(FB_WAVES * 64, FB_WAVES / 4) void pwattn_fwd_rw_kernel(const FwdParams p, const RwPlan pl, int wgs_per_split) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int WIMG = MMA == 2 ? 2 : 1;
+    constexpr int SROWS = NTS * 16;                                    // W rows (= output columns) of a slice
+    extern __shared__ __attribute__((aligned(16))) float wres[];       // [k32][WIMG][SROWS][16 floats = 32 bf16]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int M = (int)p.M, T = p.T, H = p.H, D = p.D;
+    const int split = blockIdx.x % pl.nsplit, g = blockIdx.x / pl.nsplit;
+    const int k0 = split * SROWS;                                       // first output column of the slice
+    const int K = pl.k32;
+
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, p.wp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.t), 0, p.t_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.h), 0, p.h_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.h_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v), 0, p.t_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w2), 0, D * 4, 0x00020000);
+
+    // ---- once per workgroup: the slice's W_p image -> LDS (1-KiB pieces of 16 rows), then ONE barrier
+    const int npiece = K * WIMG * NTS;
+    for (int pc = wave; pc < npiece; pc += FB_WAVES) {
+        const int ci = pc / NTS, rt = pc - ci * NTS;                   // ci = c * WIMG + img
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(wres + pc * 256), 16, lane * 16,
+                                                 (ci * pl.rows + k0 + rt * 16) * 64, 0, 0);
+    }
+    __syncthreads();                                                    // waits for this wave's DMA (vmcnt(0)), then the barrier
+
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int rslot = 4 * (q ^ swz4(r16));
+    const float b2 = split == 0 ? p.b2[0] : 0.f;
+    const int ntile = (M + 15) >> 4;
+    const int stride = wgs_per_split * FB_WAVES;
+
+    for (int tile = g * FB_WAVES + wave; tile < ntile; tile += stride) {
+        const int m = tile * 16 + r16;
+        const unsigned mm = m < M ? (unsigned)m : 0u;
+        const unsigned bt = mm / (unsigned)H;
+        const unsigned hr = (bt / (unsigned)T) * H + (mm - bt * H);
+        const unsigned voff_t = m < M ? (bt * p.ldt + 4 * q) * 4u : OOB;
+        const unsigned voff_h = m < M ? (hr * p.ldh + 4 * q) * 4u : OOB;
+        const unsigned voff_u = m < M ? (hr * p.ldu + 4 * q) * 4u : OOB;
+        const unsigned voff_v = m < M ? (bt * p.ldv + 4 * q) * 4u : OOB;
+
+        f32x4 ta[2], tb[2], ha[2], hb[2];                              // two chunk sets of this lane's operand columns
+        auto load_th = [&](int c, int set) {
+            if ((NRM_DIAG_RW & 4) && c > 1) return;
+            ta[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_t, voff_t, c * 128, 0));
+            tb[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_t, voff_t, c * 128 + 64, 0));
+            ha[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, voff_h, c * 128, 0));
+            hb[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, voff_h, c * 128 + 64, 0));
+        };
+        load_th(0, 0);
+        // accumulators start at u[b,h,k] + v[b,t,k]
+        f32x4 acc[NTS];
+#pragma unroll
+        for (int it = 0; it < NTS; ++it) {
+            const int kb = (k0 + it * 16) * 4;
+            const f32x4 uu = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, voff_u, kb, 0));
+            const f32x4 vv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, voff_v, kb, 0));
+            acc[it] = (k0 + it * 16 + 4 * q < D) ? uu + vv : zero4;
+            if (NRM_DIAG_RW & 8) acc[it] = zero4;
+        }
+
+        auto compute = [&](int c, int set) {
+            const f32x4 lo = ta[set] * ha[set], hi = tb[set] * hb[set];
+            bf16x8 pf, pl2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pf[e] = (__bf16)lo[e]; pf[4 + e] = (__bf16)hi[e];
+                if (MMA == 2) { pl2[e] = (__bf16)(lo[e] - (float)pf[e]); pl2[4 + e] = (__bf16)(hi[e] - (float)pf[4 + e]); }
+            }
+            const float* buf = wres + c * (WIMG * SROWS * 16);
+            // W fragments are read LA tiles ahead of their MFMAs (a 16x16x32 MFMA issues every 16 cycles, an LDS read takes 64+)
+            constexpr int LA = MMA == 2 ? 3 : 6;
+            auto rd = [&](int it, int im) { return *reinterpret_cast<const bf16x8*>(&buf[(im * SROWS + it * 16 + r16) * 16 + rslot]); };
+            bf16x8 af[NTS], al[NTS];
+#pragma unroll
+            for (int it = 0; it < LA && it < NTS; ++it) { af[it] = rd(it, 0); if (MMA == 2) al[it] = rd(it, 1); }
+#pragma unroll
+            for (int it = 0; it < NTS; ++it) {
+                if (it + LA < NTS) { af[it + LA] = rd(it + LA, 0); if (MMA == 2) al[it + LA] = rd(it + LA, 1); }
+                if (MMA == 2) {                                        // small terms first
+                    acc[it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[it], pf, acc[it], 0, 0, 0);
+                    acc[it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[it], pl2, acc[it], 0, 0, 0);
+                }
+                acc[it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[it], pf, acc[it], 0, 0, 0);
+            }
+        };
+        for (int c = 0; c < K; c += 2) {
+            if (c + 1 < K) load_th(c + 1, 1);
+            compute(c, 0);
+            if (c + 1 >= K) break;
+            if (c + 2 < K) load_th(c + 2, 0);
+            compute(c + 1, 1);
+        }
+
+        // ---- epilogue: optional z store ; GELU ; partial fc2 dot over the slice's columns
+        const int rows_here = min(16, M - tile * 16);
+        const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(
+            SAVE_Z ? p.z + (size_t)tile * 16 * D : nullptr, 0, SAVE_Z ? rows_here * D * 4 : 0, 0x00020000);
+        // fc2 weights of the slice's columns (0 beyond D; L1-resident): requested together, one round trip
+        f32x4 ww[NTS];
+#pragma unroll
+        for (int it = 0; it < NTS; ++it)
+            ww[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, 16 * q, (k0 + it * 16) * 4, 0));
+        float s_part = 0.f;
+#pragma unroll
+        for (int it = 0; it < NTS; ++it) {
+            const f32x4 zz = acc[it];
+            if (SAVE_Z && !(NRM_DIAG_RW & 1) && k0 + it * 16 + 4 * q < D)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zz), rs_z, (unsigned)(r16 * D + 4 * q) * 4u, (k0 + it * 16) * 4, 0);
+            if (NRM_DIAG_RW & 2) s_part += ww[it][0] * zz[0] + ww[it][1] * zz[1] + ww[it][2] * zz[2] + ww[it][3] * zz[3];
+            else s_part += ww[it][0] * gelu_f(zz[0]) + ww[it][1] * gelu_f(zz[1]) + ww[it][2] * gelu_f(zz[2]) + ww[it][3] * gelu_f(zz[3]);
+        }
+        const float v = sum_rows4(s_part) + b2;
+        if (q == 0 && m < M) {
+            if (pl.nsplit == 1) p.s[m] = v; else atomicAdd(p.s + m, v);
+        }
+    }
+#endif
+}
+
+static int rw_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        return cus > 0 ? cus : 256;
+    }();
+    return n;
+}
+
+template <int NTS>
+static hipError_t launch_rw(const FwdParams& p, const RwPlan& pl, int mma, hipStream_t st) {
+    const int ntile = (int)((p.M + 15) / 16);
+    if (ntile <= 0) return hipSuccess;
+    int wgs = rw_cus() / pl.nsplit;                                     // one persistent workgroup per CU, CUs shared evenly by the slices
+    if (wgs < 1) wgs = 1;
+    if ((long)wgs * FB_WAVES > ntile) wgs = (ntile + FB_WAVES - 1) / FB_WAVES;
+    const size_t shm = (size_t)pl.k32 * pl.wimg * NTS * 1024;
+    if (pl.nsplit > 1) {                                                // the slices ADD their partial scores
+        hipError_t e = hipMemsetAsync(p.s, 0, (size_t)p.M * sizeof(float), st);
+        if (e != hipSuccess) return e;
+    }
+    const dim3 grid((unsigned)(wgs * pl.nsplit)), block(FB_WAVES * 64);
+#define NRM_RW(SZ, M_)                                                                                                   \
+    {                                                                                                                    \
+        auto k = pwattn_fwd_rw_kernel<NTS, SZ, M_>;                                                                      \
+        static bool attr_set = false;                        /* once per instantiation (idempotent if raced) */        \
+        if (!attr_set) {                                                                                                 \
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS_BUDGET);  \
+            if (e != hipSuccess) return e;                                                                               \
+            attr_set = true;                                                                                             \
+        }                                                                                                                \
+        hipLaunchKernelGGL(k, grid, block, shm, st, p, pl, wgs);                                                         \
+    }
+    if (mma == 2) { if (p.z) NRM_RW(true, 2) else NRM_RW(false, 2) }
+    else          { if (p.z) NRM_RW(true, 1) else NRM_RW(false, 1) }
+#undef NRM_RW
+    return hipGetLastError();
+}
+
+hipError_t pwattn_fwd_bf16_launch(const FwdParams& p, int mma, hipStream_t st) {
+    const RwPlan pl = pwattn_rw_plan(p.D, mma);
+    switch (pl.nts) {
+        case 1:  return launch_rw<1>(p, pl, mma, st);
+        case 2:  return launch_rw<2>(p, pl, mma, st);
+        case 3:  return launch_rw<3>(p, pl, mma, st);
+        case 4:  return launch_rw<4>(p, pl, mma, st);
+        case 5:  return launch_rw<5>(p, pl, mma, st);
+        case 6:  return launch_rw<6>(p, pl, mma, st);
+        case 8:  return launch_rw<8>(p, pl, mma, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace nrm
