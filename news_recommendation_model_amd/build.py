@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnrm_hotpath.so")
-SOURCES = ["pwattn_fwd.hip", "pwattn_fwd_bf16.hip", "pwattn_bwd.hip", "gemm.hip", "head.hip", "pool_loss.hip", "frontend.hip", "capi.hip"]
+SOURCES = ["pwattn_fwd.hip", "pwattn_fwd_rw.hip", "pwattn_bwd.hip", "gemm.hip", "head.hip", "pool_loss.hip", "frontend.hip", "capi.hip"]
 
 
 def _hipcc():

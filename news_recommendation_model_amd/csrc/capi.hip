@@ -56,7 +56,8 @@ long nrm_pwattn_packed_floats(int D) {
     const nrm::FwdPlan pl = nrm::pwattn_fwd_plan(D);
     // fp32: kchunks 16-column chunks of rows x 64 B.  bf16 / bf16x3 (pwattn_fwd_bf16.hip): k32 chunks x (1 | 2) images x plan
     // rows x 64 B, where the resident-W plan may pad the rows up to one more slice -- size for the largest of the three
-    const long f32 = (long)pl.kchunks * pl.rows * 16;
+    const nrm::RwPlan r0 = nrm::pwattn_rw_plan(D, NRM_MMA_F32);
+    const long f32 = (long)pl.kchunks * (pl.rows > r0.rows ? pl.rows : r0.rows) * 16;
     const nrm::RwPlan r3 = nrm::pwattn_rw_plan(D, NRM_MMA_BF16X3), r1 = nrm::pwattn_rw_plan(D, NRM_MMA_BF16);
     const long b3 = (long)r3.k32 * 2 * r3.rows * 16, b1 = (long)r1.k32 * r1.rows * 16;
     const long need = f32 > b3 ? (f32 > b1 ? f32 : b1) : (b3 > b1 ? b3 : b1);
@@ -92,7 +93,7 @@ int nrm_pwattn_fwd(const float* t, const float* h, const float* u, const float* 
     p.wp_bytes = (unsigned)(nrm_pwattn_packed_floats(D) * 4);
     p.t_bytes = (unsigned)((long)B * T * D * 4);
     p.h_bytes = (unsigned)((long)B * H * D * 4);
-    if (mma != NRM_MMA_F32 && nrm::pwattn_rw_plan(D, mma).nts == 0)
+    if (mma != NRM_MMA_F32 && !nrm::pwattn_fwd_uses_rw(D, mma))
         return fail(NRM_EINVAL, "nrm_pwattn_fwd: D=%d is too wide for the bf16 forward (one 16-column slice of W_p must fit the LDS)", D);
     p.rows = pl.rows; p.kchunks = pl.kchunks; p.nchunks = pl.nchunks;
     return check_hip(nrm::pwattn_fwd_launch(p, pl, mma, (hipStream_t)stream), "pwattn_fwd");

@@ -27,11 +27,12 @@ struct FwdPlan { int NT, MT, nchunks, rows, kchunks; };
 FwdPlan pwattn_fwd_plan(int D);
 hipError_t pwattn_fwd_launch(const FwdParams& p, const FwdPlan& pl, int mma, hipStream_t st);
 hipError_t pack_wp_launch(const float* w, int ldw, int D, const FwdPlan& pl, int mma, float* packed, hipStream_t st);
-// bf16 matrix cores (pwattn_fwd_bf16.hip): mma = 1 (bf16 operands) or 2 (bf16x3: hi + lo split).  The output columns are cut
-// into nsplit slices of nts 16-column tiles whose whole bf16 image stays resident in LDS (persistent workgroups).
-struct RwPlan { int nts, nsplit, rows, k32, wimg; };      // rows = padded rows of the packed image = nsplit * nts * 16
+// resident-W forward (pwattn_fwd_rw.hip): mma = 0 (fp32 MFMA), 1 (bf16 operands) or 2 (bf16x3: hi + lo split).  The output
+// columns are cut into nsplit slices of nts 16-column tiles whose whole image stays resident in LDS (persistent workgroups).
+struct RwPlan { int nts, nsplit, rows, k32, wimg; };      // rows = padded rows of the packed image = nsplit * nts * 16; k32 = chunks
 RwPlan pwattn_rw_plan(int D, int mma);
-hipError_t pwattn_fwd_bf16_launch(const FwdParams& p, int mma, hipStream_t st);
+bool pwattn_fwd_uses_rw(int D, int mma);                  // which forward (and which packed layout) a call takes
+hipError_t pwattn_fwd_rw_launch(const FwdParams& p, int mma, hipStream_t st);
 hipError_t pack_wp_bf16_launch(const float* w, int ldw, int D, int mma, float* packed, hipStream_t st);
 
 // ---- backward (pwattn_bwd.hip)

@@ -267,7 +267,7 @@ static hipError_t launch_fwd_t(const FwdParams& p, hipStream_t st) {
 }
 
 hipError_t pwattn_fwd_launch(const FwdParams& p, const FwdPlan& pl, int mma, hipStream_t st) {
-    if (mma) return pwattn_fwd_bf16_launch(p, mma, st);
+    if (pwattn_fwd_uses_rw(p.D, mma)) return pwattn_fwd_rw_launch(p, mma, st);
     switch (pl.NT) {
         case 4:  return launch_fwd_t<4, 4>(p, st);
         case 6:  return launch_fwd_t<6, 4>(p, st);
@@ -283,11 +283,24 @@ hipError_t pwattn_fwd_launch(const FwdParams& p, const FwdPlan& pl, int mma, hip
     return hipErrorInvalidValue;
 }
 
+// bf16 forms: always the resident-W forward (pwattn_fwd_rw.hip).  fp32: only where the WHOLE W_p fits one LDS slice
+// (D <= 128; reference default D = 64: 0.128 -> 0.104 ms); with several slices the chunk-streaming kernel below is faster
+// (measured at C3, D = 400, 5 slices: 4.32 vs 4.13 ms; C5, D = 768: 20.5 vs 19.4 ms) and keeps the scores free of float
+// atomics.  NRM_FWD_RW=0 / =2 force the streaming / the resident form for fp32.
+bool pwattn_fwd_uses_rw(int D, int mma) {
+    static const int mode = [] { const char* e = getenv("NRM_FWD_RW"); return e ? atoi(e) : 1; }();
+    const RwPlan pl = pwattn_rw_plan(D, mma);
+    if (pl.nts == 0) return false;
+    if (mma != 0) return true;
+    return mode == 2 || (mode == 1 && pl.nsplit == 1);
+}
+
 hipError_t pack_wp_launch(const float* w, int ldw, int D, const FwdPlan& pl, int mma, float* packed, hipStream_t st) {
     if (mma) return pack_wp_bf16_launch(w, ldw, D, mma, packed, st);
-    const long total = (long)pl.kchunks * pl.rows * 16;
+    const int rows = pwattn_fwd_uses_rw(D, 0) ? pwattn_rw_plan(D, 0).rows : pl.rows;       // same image, the kernel's row padding
+    const long total = (long)pl.kchunks * rows * 16;
     const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-    hipLaunchKernelGGL(pack_wp_kernel, dim3(blocks), dim3(256), 0, st, w, ldw, D, pl.rows, pl.kchunks, packed);
+    hipLaunchKernelGGL(pack_wp_kernel, dim3(blocks), dim3(256), 0, st, w, ldw, D, rows, pl.kchunks, packed);
     return hipGetLastError();
 }
 

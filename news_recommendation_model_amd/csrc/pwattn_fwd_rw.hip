@@ -1,6 +1,7 @@
-// Pointwise history attention, forward, bf16 matrix cores (NRM_MMA_BF16 / NRM_MMA_BF16X3).  gfx950 / MI355X only.
+// Pointwise history attention, forward, "resident W_p" form: fp32 MFMA (NRM_MMA_F32) and bf16 matrix cores (NRM_MMA_BF16 /
+// NRM_MMA_BF16X3).  gfx950 / MI355X only.
 //
-// Same mathematics and the same MFMA orientation as pwattn_fwd.hip (rows m = (b,t,h) are MFMA columns, a lane ends up with
+// Same mathematics and the same MFMA orientation as the chunk-streaming kernel of pwattn_fwd.hip (rows m = (b,t,h) are MFMA columns, a lane ends up with
 // 4 consecutive k of one row; accumulators start at the fp32 u + v; epilogue = z store, exact GELU, fc2 dot), but built
 // around what changes when the contraction runs 16x (bf16) or 16/3x (bf16x3) faster than on the fp32 matrix pipe: one
 // K-chunk of MFMA work (a few hundred cycles) is far shorter than the latency of the LDS-DMA that would bring the next W_p
@@ -14,6 +15,9 @@
 //     straight into registers (two 16-byte loads each, one chunk ahead), forms t*h in fp32 and rounds once (bf16) or
 //     splits it into hi + lo (bf16x3);
 //   * with more than one slice every slice adds its partial fc2 dot to s[m] (float atomic; two addends commute exactly).
+// The fp32 form (MMA == 0: v_mfma_f32_16x16x4_f32, 16-column chunks, the fp32 image of pack_wp_kernel) gains from the same
+// structure for a different reason: its K loop is MFMA-bound, and without a barrier per chunk the epilogue of one wave (z
+// store, GELU, fc2 dot) runs under the MFMAs of the other waves of its SIMD instead of beside their epilogues.
 // timing diagnostics only (scripts/_diag/build_diag.sh): results are WRONG with any bit set
 #ifndef NRM_DIAG_RW
 #define NRM_DIAG_RW 0         // bit 0: no z store, bit 1: no GELU (plain sum), bit 2: t/h loaded once per tile (chunk 0 re-used),
@@ -68,7 +72,7 @@ constexpr int RW_LDS_BUDGET = 156 * 1024;
 RwPlan pwattn_rw_plan(int D, int mma) {
     RwPlan pl;
     const int n16 = (D + 15) / 16;
-    pl.k32 = (D + 31) / 32;
+    pl.k32 = mma ? (D + 31) / 32 : n16;                                 // reduction chunks: 32 columns (bf16) or 16 (fp32) per 64-B row
     pl.wimg = mma == 2 ? 2 : 1;
     const int tile_bytes = pl.k32 * pl.wimg * 1024;                    // one 16-column tile, all chunks and images
     int fit = RW_LDS_BUDGET / tile_bytes;
@@ -92,7 +96,8 @@ __global__ __launch_bounds__(FB_WAVES * 64, FB_WAVES / 4) void pwattn_fwd_rw_ker
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int WIMG = MMA == 2 ? 2 : 1;
     constexpr int SROWS = NTS * 16;                                    // W rows (= output columns) of a slice
-    extern __shared__ __attribute__((aligned(16))) float wres[];       // [k32][WIMG][SROWS][16 floats = 32 bf16]
+    constexpr int CB = MMA ? 128 : 64;                                 // bytes of a t / h row one reduction chunk covers
+    extern __shared__ __attribute__((aligned(16))) float wres[];       // [chunk][WIMG][SROWS][16 floats (fp32) = 32 bf16]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -139,10 +144,12 @@ __global__ __launch_bounds__(FB_WAVES * 64, FB_WAVES / 4) void pwattn_fwd_rw_ker
         f32x4 ta[2], tb[2], ha[2], hb[2];                              // two chunk sets of this lane's operand columns
         auto load_th = [&](int c, int set) {
             if ((NRM_DIAG_RW & 4) && c > 1) return;
-            ta[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_t, voff_t, c * 128, 0));
-            tb[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_t, voff_t, c * 128 + 64, 0));
-            ha[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, voff_h, c * 128, 0));
-            hb[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, voff_h, c * 128 + 64, 0));
+            ta[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_t, voff_t, c * CB, 0));
+            ha[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, voff_h, c * CB, 0));
+            if (MMA) {
+                tb[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_t, voff_t, c * CB + 64, 0));
+                hb[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, voff_h, c * CB + 64, 0));
+            }
         };
         load_th(0, 0);
         // accumulators start at u[b,h,k] + v[b,t,k]
@@ -156,7 +163,22 @@ __global__ __launch_bounds__(FB_WAVES * 64, FB_WAVES / 4) void pwattn_fwd_rw_ker
             if (NRM_DIAG_RW & 8) acc[it] = zero4;
         }
 
+        auto compute_f32 = [&](int c, int set) {
+            const f32x4 pf = ta[set] * ha[set];                         // this lane's 4 reduction columns of P[m,:] = t * h
+            const float* buf = wres + c * (SROWS * 16);
+            auto rd = [&](int it) { return *reinterpret_cast<const f32x4*>(&buf[(it * 16 + r16) * 16 + rslot]); };
+            f32x4 af = rd(0);
+#pragma unroll
+            for (int it = 0; it < NTS; ++it) {
+                f32x4 afn = af;
+                if (it + 1 < NTS) afn = rd(it + 1);                     // one tile (4 MFMAs = 128 cycles) ahead
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[it] = mfma16(af[j], pf[j], acc[it]);
+                af = afn;
+            }
+        };
         auto compute = [&](int c, int set) {
+            if (MMA == 0) { compute_f32(c, set); return; }
             const f32x4 lo = ta[set] * ha[set], hi = tb[set] * hb[set];
             bf16x8 pf, pl2;
 #pragma unroll
@@ -248,13 +270,14 @@ static hipError_t launch_rw(const FwdParams& p, const RwPlan& pl, int mma, hipSt
         }                                                                                                                \
         hipLaunchKernelGGL(k, grid, block, shm, st, p, pl, wgs);                                                         \
     }
-    if (mma == 2) { if (p.z) NRM_RW(true, 2) else NRM_RW(false, 2) }
-    else          { if (p.z) NRM_RW(true, 1) else NRM_RW(false, 1) }
+    if (mma == 2)      { if (p.z) NRM_RW(true, 2) else NRM_RW(false, 2) }
+    else if (mma == 1) { if (p.z) NRM_RW(true, 1) else NRM_RW(false, 1) }
+    else               { if (p.z) NRM_RW(true, 0) else NRM_RW(false, 0) }
 #undef NRM_RW
     return hipGetLastError();
 }
 
-hipError_t pwattn_fwd_bf16_launch(const FwdParams& p, int mma, hipStream_t st) {
+hipError_t pwattn_fwd_rw_launch(const FwdParams& p, int mma, hipStream_t st) {
     const RwPlan pl = pwattn_rw_plan(p.D, mma);
     switch (pl.nts) {
         case 1:  return launch_rw<1>(p, pl, mma, st);
