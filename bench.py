@@ -37,7 +37,9 @@ import torch.distributed as dist
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA (the 5 PF headline figure includes 2:1 sparsity)
 HBM_PEAK_GBS = 8000.0             # same guide: HBM3E spec peak (6.3 TB/s measured achievable)
-PMC_TRAFFIC_FILES = {"C3-large": "r2_c3_pmc_traffic.json", "C5-long": "r2_c5_pmc_traffic.json", "C2-small": "r2_c2_pmc_traffic.json"}
+# (workload, dtype) -> committed rocprofv3 --pmc summary of the same bench command (scripts/collect_profiles.sh + pmc_summary.py)
+PMC_TRAFFIC_FILES = {("C3-large", "f32"): "r2_c3_pmc_traffic.json", ("C5-long", "f32"): "r2_c5_pmc_traffic.json",
+                     ("C2-small", "bf16x3"): "r2_c2_bf16x3_pmc_traffic.json"}
 
 
 def parse():
@@ -393,7 +395,7 @@ def main():
     # is stale: traffic is then null and the note says so.
     traffic, traffic_note = None, "no committed PMC profile for this workload"
     from news_recommendation_model_amd import build as _build
-    tpath = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILES.get(args.workload, ""))
+    tpath = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILES.get((args.workload, args.dtype), ""))
     if not args.batch and os.path.isfile(tpath):
         try:
             prof = json.load(open(tpath))
