@@ -32,6 +32,7 @@ static const int kTargetWaves = 2048;
 // dt/dW pass 5.81 -> 5.56 ms at 3 rounds; every split of the dW pass costs one [D,D] partial slab).
 // NRM_BT_WAVES / NRM_BH_WAVES override them for tuning.
 static const int kBtWaves = 6144;
+static const int kBtMinGroups = 96;     // groups per split of the dt/dW pass (each split = one [D, D] slab of dW_p)
 static const int kBhWaves = 12288;
 static const int kTnWaves = 4096;      // gemm_tn (dW = dY^T X): NRM_TN_WAVES overrides
 
@@ -111,7 +112,7 @@ int nrm_pwattn_bwd_nsplit(int B, int T, int H, int D) {
     if (B <= 0 || T <= 0 || H <= 0 || D <= 0) return 0;
     int tw1 = kBtWaves;
     if (const char* e = getenv("NRM_BT_WAVES")) tw1 = atoi(e);
-    return nrm::bwd_e_plan(D, B * T, tw1).nsplit;
+    return nrm::bwd_e_plan(D, B * T, tw1, kBtMinGroups).nsplit;
 }
 
 int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, const float* wp, int ldwp,
@@ -135,7 +136,7 @@ int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, con
         p.G = B * T; p.G2 = T; p.R = H; p.D = D;
         int tw1 = kBtWaves;
         if (const char* e = getenv("NRM_BT_WAVES")) tw1 = atoi(e);
-        const nrm::BwdEPlan pl = nrm::bwd_e_plan(D, p.G, tw1);
+        const nrm::BwdEPlan pl = nrm::bwd_e_plan(D, p.G, tw1, kBtMinGroups);
         if (int rc = check_hip(nrm::bwd_e_launch(p, pl, true, mma, (hipStream_t)stream), "bwd_e pass 1")) return rc;
     }
     // pass 2: groups (b,h); rows r = t.  X_g = dz[b,:,h,:], Y_g = t[b];  out = dh

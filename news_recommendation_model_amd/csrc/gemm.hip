@@ -337,7 +337,10 @@ GemmTnPlan gemm_tn_plan(int ncols_i, int ncols_j, int R, int target_waves) {
     const int tiles = pl.nti * pl.ntj;
     int ns = target_waves / tiles / 4 * 4;
     if (ns < 4) ns = 4;
-    const int max_ns = (R + 63) / 64;                 // at least 64 rows per split
+    // at least 128 rows per split: every split costs a [ncols_j x ldws] partial slab that is written and read back by the
+    // slab reduction (C2-small, 16 384 x 256 x 256: 256 splits of 64 rows = 67 MB of slabs for a 256 KB gradient; halving
+    // them took the step from 5.99 to 5.73 ms); the large shapes (C3: 960 / 320 rows per split) are not affected
+    const int max_ns = (R + 127) / 128;
     if (ns > max_ns) ns = max_ns < 1 ? 1 : max_ns;
     pl.rps = ((R + ns - 1) / ns + 3) / 4 * 4;        // multiple of 4 rows
     if (pl.rps < 4) pl.rps = 4;

@@ -697,7 +697,10 @@ __global__ __launch_bounds__(256, 2) void bwd_e_pipe_kernel(const BwdEParams p) 
 #endif
 }
 
-BwdEPlan bwd_e_plan(int D, int G, int target_waves) {
+// min_gps: lower bound on the groups a split walks.  The dt/dW pass passes 96: every split of it writes a [D, D] partial
+// slab of dW_p (C2-small at the old 40 groups per split: 384 slabs = 100 MB for a 256 KB gradient; 5.73 -> 5.68 ms per step
+// with 120); C3's 126 groups per split are unaffected.
+BwdEPlan bwd_e_plan(int D, int G, int target_waves, int min_gps) {
     const int n16 = (D + 15) / 16;
     const int c5 = (n16 + 4) / 5 * 5, c4 = (n16 + 3) / 4 * 4;
     BwdEPlan pl;
@@ -709,6 +712,12 @@ BwdEPlan bwd_e_plan(int D, int G, int target_waves) {
     // at most the number of resident wave slots (ONE round: one task more would add a whole second round) or
     // several times it (many small tasks, dynamically balanced) -- see capi.hip.
     int ns = target_waves / tiles / 4 * 4;
+    // too few groups per split: fall back to exactly ONE round of wave tasks (2048 resident wave slots at 2 waves/SIMD) -- never
+    // fewer tasks than the chip holds, never a second, mostly empty round
+    if (min_gps > 1 && ns > G / min_gps) {
+        const int one_round = 2048 / tiles / 4 * 4;
+        if (one_round >= 4 && one_round < ns) ns = one_round;
+    }
     if (ns < 4) ns = 4;
     if (ns > G) ns = G > 0 ? G : 1;
     pl.gps = (G + ns - 1) / ns;
