@@ -146,6 +146,12 @@ int nrm_loss_fwd_bwd(const float* out, const float* label, const long* user_id, 
  * n % 4 == 0, 16-byte aligned buffers. */
 int nrm_adam_step(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, int zero_grad, nrm_stream_t stream);
+/* n gradient tensors -> their slots of the flat gradient buffer in ONE launch (reference train.py:73-74: what sits between
+ * loss.backward() and optimizer.step(); with data parallelism, what the single all-reduce then runs on).  srcs / offsets /
+ * counts are HOST arrays (copied into the kernel arguments at call time): flat[offsets[i] .. +counts[i]) = srcs[i][0 ..
+ * counts[i]); a NULL source zero-fills its slot.  Contiguous fp32 sources. */
+int nrm_gather_flat(const float* const* srcs, const long* offsets, const long* counts, int n, float* flat, long flat_n,
+                    nrm_stream_t stream);
 /* the same with the step counter on the device (state = float[4]: {step, 1-beta1^step, sqrt(1-beta2^step), -},
  * zero-initialised by the caller, advanced by the call): safe to capture in a hipGraph and replay */
 int nrm_adam_step_dev(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,

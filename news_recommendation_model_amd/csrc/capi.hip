@@ -309,6 +309,26 @@ int nrm_adam_step(float* p, float* g, float* m, float* v, long n, float lr, floa
 }
 
 
+int nrm_gather_flat(const float* const* srcs, const long* offsets, const long* counts, int n, float* flat, long flat_n,
+                    nrm_stream_t stream) {
+    if ((n > 0 && (!srcs || !offsets || !counts)) || !flat) return fail(NRM_EINVAL, "nrm_gather_flat: null pointer");
+    if (n < 0) return fail(NRM_EINVAL, "nrm_gather_flat: n=%d", n);
+    for (int lo = 0; lo < n; lo += nrm::GATHER_MAX) {
+        const int m = n - lo < nrm::GATHER_MAX ? n - lo : nrm::GATHER_MAX;
+        nrm::GatherTable tab;
+        long mx = 0;
+        for (int i = 0; i < m; ++i) {
+            if (offsets[lo + i] < 0 || counts[lo + i] < 0 || offsets[lo + i] + counts[lo + i] > flat_n)
+                return fail(NRM_EINVAL, "nrm_gather_flat: entry %d (offset %ld, count %ld) leaves the flat buffer of %ld floats",
+                            lo + i, offsets[lo + i], counts[lo + i], flat_n);
+            tab.src[i] = srcs[lo + i]; tab.off[i] = offsets[lo + i]; tab.cnt[i] = counts[lo + i];
+            if (counts[lo + i] > mx) mx = counts[lo + i];
+        }
+        if (int rc = check_hip(nrm::gather_flat_launch(tab, m, mx, flat, (hipStream_t)stream), "gather_flat")) return rc;
+    }
+    return NRM_OK;
+}
+
 int nrm_adam_step_dev(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                       float weight_decay, float* state, int zero_grad, nrm_stream_t stream) {
     if (!p || !g || !m || !v || !state) return fail(NRM_EINVAL, "nrm_adam_step_dev: null pointer");

@@ -311,6 +311,35 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, fl
     }
 }
 
+// Gradients of up to 128 parameter tensors -> their slots of ONE flat buffer in a single launch (the table travels in the
+// kernel arguments: no device-side table to keep coherent, and a hipGraph capture bakes the pointers of its own pool).
+// blockIdx.y = tensor; a null source zero-fills its slot (a parameter that received no gradient).  Replaces one
+// AccumulateGrad add_ launch per parameter (38 per step) with one launch.
+__global__ __launch_bounds__(256) void gather_flat_kernel(const GatherTable tab, float* __restrict__ flat) {
+    const int i = blockIdx.y;
+    const float* __restrict__ src = tab.src[i];
+    float* __restrict__ dst = flat + tab.off[i];
+    const long n = tab.cnt[i];
+    const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    const long stride = (long)gridDim.x * blockDim.x;
+    if (vec) {
+        const long n4 = n >> 2;
+        for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < n4; j += stride)
+            reinterpret_cast<f32x4*>(dst)[j] = src ? reinterpret_cast<const f32x4*>(src)[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+        for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) dst[j] = src ? src[j] : 0.f;
+    }
+}
+
+hipError_t gather_flat_launch(const GatherTable& tab, int n, long max_count, float* flat, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    long bx = (max_count / 4 + 255) / 256;
+    if (bx > 64) bx = 64;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(gather_flat_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, tab, flat);
+    return hipGetLastError();
+}
+
 static unsigned adam_blocks(long n) {
     long blocks = ((n >> 2) + 255) / 256;
     if (blocks > 2048) blocks = 2048;

@@ -13,6 +13,9 @@ hipError_t adam_launch(float* p, float* g, float* m, float* v, long n, float lr,
                        float wd, int step, int zero_grad, hipStream_t st);
 hipError_t adam_dev_launch(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                            float wd, float* state, int zero_grad, hipStream_t st);
+constexpr int GATHER_MAX = 128;
+struct GatherTable { const float* src[GATHER_MAX]; long off[GATHER_MAX]; long cnt[GATHER_MAX]; };      // 3 KB of kernel arguments
+hipError_t gather_flat_launch(const GatherTable& tab, int n, long max_count, float* flat, hipStream_t st);
 hipError_t row_auc_launch(const float* score, const float* label, const int* len, int B, int T, float* auc, int* top1,
                           hipStream_t st);
 }  // namespace nrm

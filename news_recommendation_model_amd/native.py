@@ -43,6 +43,7 @@ SIGNATURES = {
     "nrm_loss_fwd_bwd": (_c_i, [_c_fp] * 4 + [_c_l, ctypes.c_float, _c_i, _c_i] + [_c_fp] * 5),
     "nrm_adam_step": (_c_i, [_c_fp] * 4 + [_c_l] + [ctypes.c_float] * 5 + [_c_i, _c_i, _c_fp]),
     "nrm_adam_step_dev": (_c_i, [_c_fp] * 4 + [_c_l] + [ctypes.c_float] * 5 + [_c_fp, _c_i, _c_fp]),
+    "nrm_gather_flat": (_c_i, [_c_fp, _c_fp, _c_fp, _c_i, _c_fp, _c_l, _c_fp]),
     "nrm_row_auc": (_c_i, [_c_fp] * 3 + [_c_i, _c_i] + [_c_fp] * 3),
     "nrm_frontend_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,  _c_fp, _c_i, _c_i,  _c_fp, _c_fp, _c_i,
                                  _c_fp, _c_i, _c_i,  _c_fp, _c_fp, _c_fp, _c_fp,  _c_i, _c_i, _c_i, _c_i, _c_i,

@@ -49,11 +49,14 @@ def make_optimizer(model, lr=1e-3):
 class FlatAdam:
     """train.py:48's Adam(lr, weight_decay=1e-5) over ONE flat fp32 buffer.
 
-    Parameters and their ``.grad`` are re-seated as views into two flat buffers (values are preserved, the
-    Module's ``state_dict`` keeps working), so ``step()`` + ``zero_grad()`` is a single HIP kernel launch over
-    all weights and the data-parallel gradient all-reduce runs on ``flat_grad`` without a gather copy."""
+    Parameters are re-seated as views into one flat buffer (values are preserved, the Module's ``state_dict`` keeps
+    working).  ``loss.backward()`` leaves every parameter's gradient where autograd produced it (``p.grad`` starts as
+    None, so AccumulateGrad adopts the tensor instead of launching an ``add_`` per parameter); ``collect_grads()`` then
+    gathers all of them into ``flat_grad`` with ONE launch (C ABI ``nrm_gather_flat``), the data-parallel all-reduce runs on
+    that buffer without a copy, and ``step()`` is one fused Adam launch over all weights."""
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5):
+        import ctypes
         from . import native
         native.load()
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -65,6 +68,7 @@ class FlatAdam:
             offs.append(n)
             n += (p.numel() + 3) // 4 * 4                      # every parameter starts 16-byte aligned
         self.n = n
+        self.offsets = offs
         self.flat_param = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -73,7 +77,12 @@ class FlatAdam:
             view = self.flat_param[o:o + p.numel()].view_as(p)
             view.copy_(p.data)
             p.data = view
-            p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+            p.grad = None
+        k = len(self.params)
+        self._srcs = (ctypes.c_void_p * k)()
+        self._offs = (ctypes.c_long * k)(*offs)
+        self._cnts = (ctypes.c_long * k)(*[p.numel() for p in self.params])
+        self._collected = False
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         # {step, 1-b1^step, sqrt(1-b2^step), -} lives on the device: the step is graph-capturable
         self.state = torch.zeros(4, dtype=torch.float32, device=dev)
@@ -87,17 +96,50 @@ class FlatAdam:
     def steps(self):
         return int(self.state[0].item())
 
+    def grad_view(self, p_index):
+        """The slot of parameter ``p_index`` in ``flat_grad`` (valid after ``collect_grads()``)."""
+        p, o = self.params[p_index], self.offsets[p_index]
+        return self.flat_grad[o:o + p.numel()].view_as(p)
+
+    def collect_grads(self):
+        """All ``p.grad`` -> ``flat_grad`` (a parameter without a gradient contributes zeros), one launch; the per-parameter
+        gradient tensors are released.  Idempotent until the next ``step()`` / ``zero_grad()``."""
+        if self._collected:
+            return
+        from . import native
+        keep = []
+        for i, p in enumerate(self.params):
+            g = p.grad
+            if g is None:
+                self._srcs[i] = None
+                continue
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                g = g.to(torch.float32).contiguous()
+            keep.append(g)
+            self._srcs[i] = g.data_ptr()
+        native.call("nrm_gather_flat", self._srcs, self._offs, self._cnts, len(self.params), native.ptr(self.flat_grad), self.n,
+                    native.stream_ptr())
+        for p in self.params:
+            p.grad = None
+        self._collected = True
+
     def step(self, zero_grad=True):
         from . import ops
+        self.collect_grads()
         ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.state,
                       float(self.param_groups[0]["lr"]), float(self.betas[0]), float(self.betas[1]), float(self.eps),
                       float(self.weight_decay), bool(zero_grad))          # torch.ops.nrm.adam_step -> nrm_adam_step_dev
+        self._collected = False
 
     def zero_grad(self, set_to_none=False):
+        for p in self.params:
+            p.grad = None
         self.flat_grad.zero_()
+        self._collected = False
 
     def all_reduce_grads(self, group=None):
         """The ONE collective of a data-parallel step: sum the flat gradient over ranks, then average."""
+        self.collect_grads()
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         if world > 1:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)

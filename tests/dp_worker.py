@@ -49,7 +49,6 @@ def main(out_path):
         out = model(shard["x_history"], shard["x_target"], shard["x_global"])
         loss = model.loss(shard["user_id"], out, shard["label"])
         loss.backward()
-        local = opt.flat_grad.clone()
         p = orc.to_torch_params(sd)
         sh32 = {k: (v.float() if v.is_floating_point() else v) for k, v in shard_cpu.items()}
         loss_o, r_o, g_o = orc.train_step(p, {"step": 0, "m": {}, "v": {}}, sh32, lr=0.0)
@@ -67,6 +66,11 @@ def main(out_path):
                 worst = max(worst, e)
                 assert e < 1e-2, (k, e)
         res["grad_max_rel_err_vs_oracle"] = worst
+        opt.collect_grads()                                  # every p.grad -> its slot of the flat buffer, one launch
+        local = opt.flat_grad.clone()
+        for i, prm in enumerate(opt.params):
+            assert prm.grad is None
+        assert float(local.abs().max()) > 0
 
         # -- 2. exactly one collective, and it leaves the mean over ranks
         calls = {"n": 0}

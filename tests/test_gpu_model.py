@@ -162,6 +162,7 @@ def test_flat_adam_matches_torch_adam_and_fixture(lib):
     for (k, a), (_, b) in zip(model.named_parameters(), twin.named_parameters()):
         assert torch.allclose(a, b, rtol=0, atol=3e-4), k
     assert float(fopt.flat_grad.abs().max()) == 0.0          # zero_grad fused into the step
+    assert all(p.grad is None for p in fopt.params)          # and the per-parameter gradient tensors are released
     # state_dict round trip still works on the re-seated parameters
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     model.load_state_dict(sd)
@@ -396,3 +397,30 @@ def test_bf16_attention_train_step_matches_reference_fixture(lib, mma, name):
             worst = max(worst, e)
             assert e <= grad_tol, (k, e)
     print(name, mma, "logits rel err", e_r, "worst grad rel err", worst)
+
+
+def test_flat_adam_collects_every_gradient_with_one_launch(lib):
+    """FlatAdam.collect_grads(): the gradients autograd left on the parameters land, bit for bit, in their slots of the flat
+    buffer (C ABI nrm_gather_flat: one launch for all 38 tensors); a parameter that received no gradient contributes
+    zeros; the padding between slots stays zero."""
+    from news_recommendation_model_amd import trainer
+    case, model, tb, batch, fx = _model_and_batch("tiny_train")
+    model.train()
+    opt = trainer.FlatAdam(model)
+    out = model(tb["x_history"], tb["x_target"], tb["x_global"])
+    model.loss(tb["user_id"], out, tb["label"]).backward()
+    grads = [p.grad.clone() if p.grad is not None else None for p in opt.params]
+    assert sum(g is not None for g in grads) >= len(grads) - 1
+    grads[3] = None
+    opt.params[3].grad = None                                 # pretend this one got nothing
+    opt.flat_grad.fill_(7.0)                                  # stale contents must be overwritten
+    opt.collect_grads()
+    torch.cuda.synchronize()
+    covered = torch.zeros(opt.n, dtype=torch.bool, device="cuda")
+    for i, (p, g) in enumerate(zip(opt.params, grads)):
+        got = opt.grad_view(i)
+        assert torch.equal(got, g if g is not None else torch.zeros_like(p)), i
+        covered[opt.offsets[i]:opt.offsets[i] + p.numel()] = True
+    assert all(p.grad is None for p in opt.params)
+    opt.collect_grads()                                       # idempotent until the next step
+    assert torch.equal(opt.grad_view(0), grads[0])
