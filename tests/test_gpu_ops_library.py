@@ -11,8 +11,15 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-# schema (incl. the mutation annotations), fake-tensor function vs real outputs, autograd registration
-CHECKS = ("test_schema", "test_faketensor", "test_autograd_registration")
+# Full default opcheck (schema incl. mutation annotations, fake-tensor function vs real outputs, autograd registration, AOT
+# dispatch with dynamic shapes) for every op -- except the two attention ops, whose backward consumes the saved [B,T,H,D]
+# pre-activation IN PLACE by design (2.46 GB at C3: DESIGN.md §4): AOT autograd refuses graphs that mutate a saved tensor in
+# the backward, so `test_aot_dispatch_dynamic` is left out for them (and only for them).
+CHECKS_ATTN = ("test_schema", "test_faketensor", "test_autograd_registration")
+
+
+def _opcheck(op, args):
+    torch.library.opcheck(op, args)                       # all four default checks
 
 
 def _attn_args(B=2, T=3, H=5, D=16, grad=True):
@@ -35,16 +42,15 @@ def test_every_op_is_registered_under_torch_ops_nrm(lib):
 def test_opcheck_attention_and_pool(lib):
     from news_recommendation_model_amd import ops   # noqa: F401  (registers the ops)
     t, h, w1, b1, w2, b2 = _attn_args()
-    torch.library.opcheck(torch.ops.nrm.pwattn_fwd.default, (t, h, w1, b1, w2, b2, True, 0), test_utils=CHECKS)
+    torch.library.opcheck(torch.ops.nrm.pwattn_fwd.default, (t, h, w1, b1, w2, b2, True, 0), test_utils=CHECKS_ATTN)
     torch.library.opcheck(torch.ops.nrm.pwattn_fwd.default, (t.detach(), h.detach(), w1.detach(), b1.detach(), w2.detach(),
-                                                             b2.detach(), False, 1), test_utils=CHECKS)
+                                                             b2.detach(), False, 1), test_utils=CHECKS_ATTN)
     s, z = torch.ops.nrm.pwattn_fwd(t.detach(), h.detach(), w1.detach(), b1.detach(), w2.detach(), b2.detach(), True, 0)
     torch.library.opcheck(torch.ops.nrm.pwattn_bwd.default, (torch.randn_like(s), t.detach(), h.detach(), w1.detach(), w2.detach(), z, 0),
-                          test_utils=CHECKS)
+                          test_utils=CHECKS_ATTN)
     sc = torch.randn(2, 3, 5, device="cuda", requires_grad=True)
-    torch.library.opcheck(torch.ops.nrm.weighted_pool_fwd.default, (sc, h), test_utils=CHECKS)
-    torch.library.opcheck(torch.ops.nrm.weighted_pool_bwd.default, (torch.randn(2, 3, 16, device="cuda"), sc.detach(), h.detach()),
-                          test_utils=CHECKS)
+    _opcheck(torch.ops.nrm.weighted_pool_fwd.default, (sc, h))
+    _opcheck(torch.ops.nrm.weighted_pool_bwd.default, (torch.randn(2, 3, 16, device="cuda"), sc.detach(), h.detach()))
 
 
 def test_opcheck_dense_batchnorm_loss_frontend(lib):
@@ -54,24 +60,24 @@ def test_opcheck_dense_batchnorm_loss_frontend(lib):
     x = r(37, 24).requires_grad_(True)
     w, b = (0.2 * r(10, 24)).requires_grad_(True), r(10).requires_grad_(True)
     for gelu in (False, True):
-        torch.library.opcheck(torch.ops.nrm.linear_fwd.default, (x, w, b, gelu), test_utils=CHECKS)
+        _opcheck(torch.ops.nrm.linear_fwd.default, (x, w, b, gelu))
     w2, b2 = (0.2 * r(24, 10)).requires_grad_(True), r(24).requires_grad_(True)
-    torch.library.opcheck(torch.ops.nrm.mlp_gelu_fwd.default, (x, w, b, w2, b2, None), test_utils=CHECKS)
+    _opcheck(torch.ops.nrm.mlp_gelu_fwd.default, (x, w, b, w2, b2, None))
     m = r(37, 24).requires_grad_(True)
-    torch.library.opcheck(torch.ops.nrm.mlp_gelu_fwd.default, (x, w, b, w2, b2, m), test_utils=CHECKS)
+    _opcheck(torch.ops.nrm.mlp_gelu_fwd.default, (x, w, b, w2, b2, m))
     # BatchNorm: the statistics op mutates the running buffers (declared), the apply op is functional with autograd
     rm, rv = torch.zeros(24, device="cuda"), torch.ones(24, device="cuda")
-    torch.library.opcheck(torch.ops.nrm.batch_norm_stats.default, (x.detach(), rm, rv, 0.1, 1e-5), test_utils=CHECKS)
+    _opcheck(torch.ops.nrm.batch_norm_stats.default, (x.detach(), rm, rv, 0.1, 1e-5))
     mean, rstd = torch.ops.nrm.batch_norm_stats(x.detach(), rm, rv, 0.1, 1e-5)
     gamma, beta = r(24).requires_grad_(True), r(24).requires_grad_(True)
-    torch.library.opcheck(torch.ops.nrm.batch_norm_apply.default, (x, mean, rstd, gamma, beta, True), test_utils=CHECKS)
+    _opcheck(torch.ops.nrm.batch_norm_apply.default, (x, mean, rstd, gamma, beta, True))
     # loss
     out = r(6, 9).requires_grad_(True)
     delta = (0.1 * r(5)).requires_grad_(True)
     label = torch.zeros(6, 9, device="cuda")
     label[torch.arange(6), torch.arange(6)] = 1
     uid = torch.tensor([0, 1, 4, 2, 2, 3], device="cuda")
-    torch.library.opcheck(torch.ops.nrm.softmax_bce_loss.default, (out, delta, label, uid, 0.95), test_utils=CHECKS)
+    _opcheck(torch.ops.nrm.softmax_bce_loss.default, (out, delta, label, uid, 0.95))
     # front end on packed rows
     dims = config.Dims.for_emb(16, 40)
     batch = synth.make_batch(dims, 3, 4, 2, seed=3, user_num=5)
@@ -81,13 +87,13 @@ def test_opcheck_dense_batchnorm_loss_frontend(lib):
         "category_embedding.0.weight", "sentiment_embedding.0.weight", "sentiment_embedding.0.bias", "type_embedding.0.weight",
         "year_embedding.0.weight", "month_embedding.0.weight", "day_embedding.0.weight", "hour_embedding.0.weight")]
     rows = torch.from_numpy(batch["x_history"]).cuda().reshape(-1, batch["x_history"].shape[-1])
-    torch.library.opcheck(torch.ops.nrm.frontend_fwd.default, (rows, True, dims.n_subcat, dims.pca_vector, *tabs), test_utils=CHECKS)
+    _opcheck(torch.ops.nrm.frontend_fwd.default, (rows, True, dims.n_subcat, dims.pca_vector, *tabs))
     # evaluation + optimizer ops
-    torch.library.opcheck(torch.ops.nrm.row_auc.default, (out.detach(), label, None), test_utils=CHECKS)
+    _opcheck(torch.ops.nrm.row_auc.default, (out.detach(), label, None))
     n = 64
     p_, g_, m_, v_ = r(n), r(n), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
     st = torch.zeros(4, device="cuda")
-    torch.library.opcheck(torch.ops.nrm.adam_step.default, (p_, g_, m_, v_, st, 1e-3, 0.9, 0.999, 1e-8, 1e-5, True), test_utils=CHECKS)
+    _opcheck(torch.ops.nrm.adam_step.default, (p_, g_, m_, v_, st, 1e-3, 0.9, 0.999, 1e-8, 1e-5, True))
 
 
 def test_ops_called_through_torch_ops_match_the_python_entry_points(lib):
