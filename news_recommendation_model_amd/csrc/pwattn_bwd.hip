@@ -22,6 +22,9 @@
 #ifndef NRM_EPI_AHEAD
 #define NRM_EPI_AHEAD 1       // dt/dW pass: W_p^T LDS reads two tiles ahead in the epilogue (0: one read, one wait, per tile)
 #endif
+#ifndef NRM_DIAG_GELU_AT_LOAD
+#define NRM_DIAG_GELU_AT_LOAD 0   // timing only: the serial contraction kernels evaluate gelu'(x) on every X operand they load (what
+#endif                            // consuming z directly -- no dz pass -- would cost them)
 #ifndef NRM_DIAG_NOEPI
 #define NRM_DIAG_NOEPI 0      // contraction kernels without the per-group epilogue
 #endif
@@ -302,6 +305,10 @@ __global__ __launch_bounds__(256, (MMA && KT > 4) || (MMA == 2 && WITH_DW) ? 1 :
             a[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx1, s * xstep, 0));
         if (DT > 4 && !(NRM_DIAG_NOLOAD == 3 && !diag_first))
             b[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, vy1, s * ystep, 0));
+        if (NRM_DIAG_GELU_AT_LOAD) {
+#pragma unroll
+            for (int e = 0; e < KT; ++e) a[e] = b[0] * gelu_grad_f(a[e]);       // ds * w2 * gelu'(z): one multiply stands in for the scale
+        }
     };
 
     // One group: on entry sets 0 and 1 hold steps 0 and 1.  After its last MFMA batch it prefetches steps 0 and 1 of
