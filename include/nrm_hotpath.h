@@ -119,9 +119,16 @@ int nrm_mul_bwd(const float* dy, int lddy, const float* g, int ldg, const float*
                 int R, int N, nrm_stream_t stream);
 int nrm_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                  float* y, int R, int N, int ld, nrm_stream_t stream);
-/* training != 0: dx = gamma*rstd*(dy - s0/R - xhat*s1/R) with s0,s1 from nrm_colreduce mode 2; else gamma*rstd*dy */
+/* training != 0: dx = gamma*rstd*(dy - s0/R - xhat*s1/R) with s0,s1 from nrm_colreduce mode 2; else gamma*rstd*dy.
+ * add (optional, same [R, ld] layout) is added to dx: the gradient the rows receive from their second consumer, the gate
+ * product of user_model.py:33, joins here instead of in a separate elementwise pass. */
 int nrm_bn_backward(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
-                    const float* s0, const float* s1, float* dx, int R, int N, int ld, int training,
+                    const float* s0, const float* s1, const float* add, float* dx, int R, int N, int ld, int training,
+                    nrm_stream_t stream);
+/* out[R, ldo] = cat(parts, dim=1) in one launch (reference models/user_model.py:31 cat[eu_H, eu_L, ec],
+ * user_invariant_interest_model.py:81,88): n <= 8 row-major sources srcs[i] [R, widths[i]] with leading dimension lds[i]
+ * (HOST arrays, copied into the kernel arguments) */
+int nrm_concat_cols(const float* const* srcs, const long* lds, const int* widths, int n, float* out, int ldo, long R,
                     nrm_stream_t stream);
 
 /* ---- weighted pool (reference models/user_invariant_interest_model.py:86-87, no softmax, no mask)

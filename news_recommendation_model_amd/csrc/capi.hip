@@ -269,14 +269,30 @@ int nrm_bn_apply(const float* x, const float* mean, const float* rstd, const flo
 }
 
 int nrm_bn_backward(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
-                    const float* s0, const float* s1, float* dx, int R, int N, int ld, int training,
+                    const float* s0, const float* s1, const float* add, float* dx, int R, int N, int ld, int training,
                     nrm_stream_t stream) {
     if (int rc = check_bn("nrm_bn_backward", R, N, ld)) return rc;
     if (!dy || !rstd || !gamma || !dx || (training && (!x || !mean || !s0 || !s1)))
         return fail(NRM_EINVAL, "nrm_bn_backward: null pointer");
-    return check_hip(nrm::bn_bwd_launch(x, dy, mean, rstd, gamma, s0, s1, dx, R, N, ld, training, (hipStream_t)stream), "bn_backward");
+    return check_hip(nrm::bn_bwd_launch(x, dy, mean, rstd, gamma, s0, s1, add, dx, R, N, ld, training, (hipStream_t)stream), "bn_backward");
 }
 
+
+int nrm_concat_cols(const float* const* srcs, const long* lds, const int* widths, int n, float* out, int ldo, long R,
+                    nrm_stream_t stream) {
+    if (!srcs || !lds || !widths || !out) return fail(NRM_EINVAL, "nrm_concat_cols: null pointer");
+    if (n < 1 || n > nrm::CONCAT_MAX || R < 0) return fail(NRM_EINVAL, "nrm_concat_cols: n=%d (1..%d) R=%ld", n, nrm::CONCAT_MAX, R);
+    nrm::ConcatTable tab = {};
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!srcs[i] || widths[i] <= 0 || lds[i] < widths[i]) return fail(NRM_EINVAL, "nrm_concat_cols: part %d (width %d, ld %ld)", i, widths[i], lds[i]);
+        tab.src[i] = srcs[i]; tab.ld[i] = lds[i]; tab.start[i] = total;
+        total += widths[i];
+    }
+    tab.n = n;
+    if (ldo < total) return fail(NRM_EINVAL, "nrm_concat_cols: ldo=%d < %d columns", ldo, total);
+    return check_hip(nrm::concat_cols_launch(tab, out, R, ldo, total, (hipStream_t)stream), "concat_cols");
+}
 
 // ------------------------------------------------------------------------------------------- pool / loss / Adam
 int nrm_pool_bmm(const float* W, long wsb, long wsi, long wsj, const float* X, float* out,

@@ -71,8 +71,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ s0,
-                                                     const float* __restrict__ s1, float* __restrict__ dx,
-                                                     long R, int N, int ld, int training) {
+                                                     const float* __restrict__ s1, const float* __restrict__ add,
+                                                     float* __restrict__ dx, long R, int N, int ld, int training) {
     const int n4 = N >> 2;
     const long total = R * n4;
     const float invR = 1.0f / (float)R;
@@ -91,6 +91,8 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ x
         } else {
             out = ga * rs * g;
         }
+        // the rows feed a second consumer besides BatchNorm (the gate product, user_model.py:33): its gradient joins here
+        if (add) out += *reinterpret_cast<const f32x4*>(add + r * ld + col);
         *reinterpret_cast<f32x4*>(dx + r * ld + col) = out;
     }
 }
@@ -167,9 +169,42 @@ hipError_t mul_bwd_launch(const float* dy, const float* g, const float* e, float
 }
 
 hipError_t bn_bwd_launch(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
-                         const float* s0, const float* s1, float* dx, long R, int N, int ld, int training, hipStream_t st) {
+                         const float* s0, const float* s1, const float* add, float* dx, long R, int N, int ld, int training,
+                         hipStream_t st) {
     if (R <= 0) return hipSuccess;
-    hipLaunchKernelGGL(bn_bwd_kernel, dim3(ew_blocks(R * (N >> 2))), dim3(256), 0, st, x, dy, mean, rstd, gamma, s0, s1, dx, R, N, ld, training);
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3(ew_blocks(R * (N >> 2))), dim3(256), 0, st, x, dy, mean, rstd, gamma, s0, s1, add, dx, R, N, ld, training);
+    return hipGetLastError();
+}
+
+// e = cat[parts...] along the columns (reference models/user_model.py:31, user_invariant_interest_model.py:81,88) in one launch:
+// up to 8 row-major [R, w_i] sources (any leading dimension) -> out[R, ldo]; columns are copied dword by dword (the part
+// widths of the head -- D_l, P, 8 -- need not be multiples of 4 in general)
+template <int VEC>      // VEC = 4: every width, leading dimension and base address is a multiple of 4 floats (16 bytes)
+__global__ __launch_bounds__(256) void concat_cols_kernel(const ConcatTable tab, float* __restrict__ out, unsigned R, int ldo, int total) {
+    const unsigned tv = (unsigned)(total / VEC);
+    const unsigned n = R * tv;                                          // host guarantees R * total < 2^31
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned r = i / tv;
+        const int c = (int)(i - r * tv) * VEC;
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < CONCAT_MAX; ++j) k += (j < tab.n && c >= tab.start[j]) ? 1 : 0;
+        const float* src = tab.src[k] + (size_t)r * tab.ld[k] + (c - tab.start[k]);
+        float* dst = out + (size_t)r * ldo + c;
+        if (VEC == 4) *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(src);
+        else *dst = *src;
+    }
+}
+
+hipError_t concat_cols_launch(const ConcatTable& tab, float* out, long R, int ldo, int total, hipStream_t st) {
+    if (R <= 0 || total <= 0) return hipSuccess;
+    if (R * total >= (1L << 31)) return hipErrorInvalidValue;
+    bool vec = (ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    for (int i = 0; i < tab.n; ++i)
+        vec = vec && (tab.start[i] & 3) == 0 && (tab.ld[i] & 3) == 0 && (reinterpret_cast<uintptr_t>(tab.src[i]) & 15) == 0;
+    vec = vec && (total & 3) == 0;
+    if (vec) hipLaunchKernelGGL(concat_cols_kernel<4>, dim3(ew_blocks(R * (total / 4))), dim3(256), 0, st, tab, out, (unsigned)R, ldo, total);
+    else     hipLaunchKernelGGL(concat_cols_kernel<1>, dim3(ew_blocks(R * total)), dim3(256), 0, st, tab, out, (unsigned)R, ldo, total);
     return hipGetLastError();
 }
 

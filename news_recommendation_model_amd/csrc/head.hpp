@@ -8,7 +8,11 @@ hipError_t colred_launch(int mode, const float* x, const float* dy, const float*
 hipError_t bn_apply_launch(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                            float* y, long R, int N, int ld, hipStream_t st);
 hipError_t bn_bwd_launch(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
-                         const float* s0, const float* s1, float* dx, long R, int N, int ld, int training, hipStream_t st);
+                         const float* s0, const float* s1, const float* add, float* dx, long R, int N, int ld, int training,
+                         hipStream_t st);
+constexpr int CONCAT_MAX = 8;
+struct ConcatTable { const float* src[CONCAT_MAX]; long ld[CONCAT_MAX]; int start[CONCAT_MAX]; int n; };
+hipError_t concat_cols_launch(const ConcatTable& tab, float* out, long R, int ldo, int total, hipStream_t st);
 hipError_t bn_finalize_launch(int stage, const float* s, float* out, float* running, int R, int N, float momentum, float eps,
                               hipStream_t st);
 hipError_t mul_bwd_launch(const float* dy, const float* g, const float* e, float* dg, float* de, long R, int N,

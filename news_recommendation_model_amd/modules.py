@@ -149,14 +149,14 @@ class UserInvariantInterestModel(nn.Module):
         lab_h, ti_h = self._embed(x_history, True)         # [B,H,D_l+2], [B,H,P]
         lab_t, ti_t = self._embed(x_target, False)         # [B,T,D_l],   [B,T,P]
         lab_h = ops.linear(lab_h, self.w1.weight, self.w1.bias)
-        ec = torch.cat((lab_t, ti_t), dim=2)
+        ec = ops.concat_last((lab_t, ti_t))
 
         s_lab = self.label_attention(lab_t, lab_h)                     # [B,T,H,1]
         s_ti = self.text_img_attention(ti_t, ti_h)
         # un-normalised weighted pool: sum_h score * history  (no softmax, padding not masked)
         pooled_lab = ops.weighted_pool(s_lab.squeeze(-1), lab_h)
         pooled_ti = ops.weighted_pool(s_ti.squeeze(-1), ti_h)
-        return torch.cat((pooled_lab, pooled_ti), dim=2), ec
+        return ops.concat_last((pooled_lab, pooled_ti)), ec
 
 
 class UserInstantInterestModel(nn.Module):
@@ -195,10 +195,15 @@ class UserModel(nn.Module):
     def forward(self, x_history, x_target, x_global):
         eu_H, ec = self.invariant_interest_model(x_history, x_target)
         eu_L = self.instant_interest_model(x_global)
-        e = torch.cat((eu_H, eu_L, ec), dim=2)
+        e = ops.concat_last((eu_H, eu_L, ec))
         B, T, N = e.shape
         rows = e.reshape(B * T, N)
-        gated = self.gate.forward_times(ops.batch_norm(rows, self.bn), rows)     # the gate multiplies the RAW concat
+        g = self.gate
+        if isinstance(g.activation, nn.GELU) and g.activation.approximate == "none":
+            # BatchNorm -> gate MLP -> product with the RAW concat as one autograd node
+            gated = ops.gate_block(rows, self.bn, g.fc1.weight, g.fc1.bias, g.fc2.weight, g.fc2.bias)
+        else:
+            gated = g.forward_times(ops.batch_norm(rows, self.bn), rows)     # the gate multiplies the RAW concat
         return self.out_mlp(self.mlp(gated)).reshape(B, T)
 
     def loss(self, id, out, label, alpha=0.95):

@@ -37,7 +37,8 @@ SIGNATURES = {
     "nrm_gemm_tn": (_c_i, [_c_fp, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_fp]),
     "nrm_colreduce": (_c_i, [_c_i] + [_c_fp] * 6 + [_c_i] * 3 + [_c_fp]),
     "nrm_bn_apply": (_c_i, [_c_fp] * 6 + [_c_i] * 3 + [_c_fp]),
-    "nrm_bn_backward": (_c_i, [_c_fp] * 8 + [_c_i] * 4 + [_c_fp]),
+    "nrm_bn_backward": (_c_i, [_c_fp] * 9 + [_c_i] * 4 + [_c_fp]),
+    "nrm_concat_cols": (_c_i, [_c_fp, _c_fp, _c_fp, _c_i, _c_fp, _c_i, _c_l, _c_fp]),
     "nrm_pool_bmm": (_c_i, [_c_fp, _c_l, _c_l, _c_l, _c_fp, _c_fp] + [_c_i] * 5 + [_c_fp]),
     "nrm_pool_rowdot": (_c_i, [_c_fp] * 3 + [_c_i] * 4 + [_c_fp]),
     "nrm_loss_fwd_bwd": (_c_i, [_c_fp] * 4 + [_c_l, ctypes.c_float, _c_i, _c_i] + [_c_fp] * 5),

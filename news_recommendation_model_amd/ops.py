@@ -542,7 +542,7 @@ batch_norm_apply = _op("batch_norm_apply", "(Tensor x, Tensor mean, Tensor rstd,
                        _bn_apply_impl, lambda x, mean, rstd, weight, bias, batch_stats: _padded_empty(x, x.shape[0], x.shape[1]))
 
 
-def _bn_bwd_impl(dy, x, mean, rstd, weight, training):
+def _bn_bwd_impl(dy, x, mean, rstd, weight, training, add=None):
     _require_gpu(dy, x)
     x = _rows(x)
     R, N = x.shape
@@ -559,8 +559,14 @@ def _bn_bwd_impl(dy, x, mean, rstd, weight, training):
     native.call("nrm_colreduce", 2, native.ptr(x), native.ptr(dy), native.ptr(mean), native.ptr(rstd),
                 native.ptr(s[0]), native.ptr(s[1]), R, N, ld, st)
     dx = torch.empty(R, ld, dtype=torch.float32, device=dev)
+    if add is not None and not (add.dim() == 2 and add.stride(1) == 1 and add.stride(0) == ld and add.dtype == torch.float32
+                                and add.data_ptr() % 16 == 0):
+        buf = torch.zeros(R, ld, dtype=torch.float32, device=dev)
+        buf[:, :N] = add
+        add = buf[:, :N]
     native.call("nrm_bn_backward", native.ptr(x), native.ptr(dy), native.ptr(mean), native.ptr(rstd), native.ptr(w),
-                native.ptr(s[0]), native.ptr(s[1]), native.ptr(dx), R, N, ld, 1 if training else 0, st)
+                native.ptr(s[0]), native.ptr(s[1]), native.ptr(add) if add is not None else None, native.ptr(dx), R, N, ld,
+                1 if training else 0, st)
     return dx[:, :N], s[1].clone(), s[0].clone()
 
 
@@ -606,6 +612,129 @@ def batch_norm(x, bn):
     else:
         mean, rstd = bn.running_mean.to(torch.float32), torch.rsqrt(bn.running_var.to(torch.float32) + bn.eps)
     return batch_norm_apply(x, mean, rstd, bn.weight, bn.bias, training)
+
+
+# ------------------------------------------------------------------------------------------------ BN -> gate MLP -> product
+def _gate_block_fwd_impl(x, mean, rstd, bn_w, bn_b, w1, b1, w2, b2, batch_stats):
+    """gate(BatchNorm(x)) * x (reference models/user_model.py:32-33) as ONE autograd node: the rows x feed BatchNorm AND the
+    product, so their two gradient contributions are joined inside the BatchNorm backward kernel instead of by a separate
+    elementwise pass over [B*T, N]."""
+    c = _bn_apply_impl(x, mean, rstd, bn_w, bn_b, batch_stats)
+    y, hidden, z, pre = _mlp_gelu_fwd_impl(c, w1, b1, w2, b2, x)
+    return y, c, hidden, z, pre
+
+
+def _gate_block_fwd_fake(x, mean, rstd, bn_w, bn_b, w1, b1, w2, b2, batch_stats):
+    M, N, N1 = x.shape[0], x.shape[1], w1.shape[0]
+    return (_padded_empty(x, M, N), _padded_empty(x, M, N), _padded_empty(x, M, N1), _padded_empty(x, M, N1), _padded_empty(x, M, N))
+
+
+gate_block_fwd = _op("gate_block_fwd", "(Tensor x, Tensor mean, Tensor rstd, Tensor bn_weight, Tensor bn_bias, Tensor fc1_weight, "
+                     "Tensor? fc1_bias, Tensor fc2_weight, Tensor? fc2_bias, bool batch_stats) -> (Tensor, Tensor, Tensor, Tensor, Tensor)",
+                     _gate_block_fwd_impl, _gate_block_fwd_fake)
+
+
+def _gate_block_bwd_impl(dy, x, mean, rstd, bn_w, c, w1, w2, hidden, z, pre, has_b1, has_b2, batch_stats):
+    dc, dw1, db1, dw2, db2, dmul = _mlp_gelu_bwd_impl(dy, c, w1, w2, hidden, z, pre, x, has_b1, has_b2, True)
+    dx, dgamma, dbeta = _bn_bwd_impl(dc, x, mean, rstd, bn_w, batch_stats, add=dmul)
+    return dx, dgamma, dbeta, dw1, db1, dw2, db2
+
+
+def _gate_block_bwd_fake(dy, x, mean, rstd, bn_w, c, w1, w2, hidden, z, pre, has_b1, has_b2, batch_stats):
+    M, N = x.shape
+    (N1, K1), (N2, K2) = w1.shape, w2.shape
+    f = lambda *shape: x.new_empty(shape, dtype=torch.float32)          # noqa: E731
+    return _padded_empty(x, M, N), f(N), f(N), f(N1, K1), f(N1) if has_b1 else f(0), f(N2, K2), f(N2) if has_b2 else f(0)
+
+
+gate_block_bwd = _op("gate_block_bwd", "(Tensor dy, Tensor x, Tensor mean, Tensor rstd, Tensor bn_weight, Tensor c, Tensor fc1_weight, "
+                     "Tensor fc2_weight, Tensor hidden, Tensor z, Tensor pre, bool has_b1, bool has_b2, bool batch_stats) -> "
+                     "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)", _gate_block_bwd_impl, _gate_block_bwd_fake)
+
+
+def _gate_block_setup(ctx, inputs, output):
+    x, mean, rstd, bn_w, bn_b, w1, b1, w2, b2, batch_stats = inputs
+    y, c, hidden, z, pre = output
+    ctx.set_materialize_grads(False)
+    ctx.flags = (b1 is not None, b2 is not None, batch_stats)
+    ctx.save_for_backward(x, mean, rstd, bn_w, c, w1, w2, hidden, z, pre)
+
+
+def _gate_block_backward(ctx, dy, _dc, _dh, _dz, _dp):
+    if dy is None:
+        return (None,) * 10
+    has_b1, has_b2, batch_stats = ctx.flags
+    dx, dgamma, dbeta, dw1, db1, dw2, db2 = gate_block_bwd(dy, *ctx.saved_tensors, has_b1, has_b2, batch_stats)
+    return dx, None, None, dgamma, dbeta, dw1, (db1 if has_b1 else None), dw2, (db2 if has_b2 else None), None
+
+
+torch.library.register_autograd("nrm::gate_block_fwd", _gate_block_backward, setup_context=_gate_block_setup, lib=_LIB)
+
+
+def gate_block(x, bn, fc1_weight, fc1_bias, fc2_weight, fc2_bias):
+    """gate(bn(x)) * x for 2-D rows x (models/user_model.py:32-33; the gate is MLP with the default exact GELU).  Falls back to
+    the separate ops for BatchNorm configurations / widths the column kernels do not take."""
+    if (x.dim() != 2 or x.shape[1] % 4 or not bn.affine or not bn.track_running_stats or bn.momentum is None
+            or x.shape[0] <= (1 if bn.training else 0) or fc2_weight.shape[0] != x.shape[1]):
+        return mlp_gelu(batch_norm(x, bn), fc1_weight, fc1_bias, fc2_weight, fc2_bias, mul=x)
+    _require_gpu(x, bn.weight, fc1_weight)
+    if bn.training:
+        bn.num_batches_tracked.add_(1)
+        mean, rstd = batch_norm_stats(x.detach(), bn.running_mean, bn.running_var, float(bn.momentum), float(bn.eps))
+    else:
+        mean, rstd = bn.running_mean.to(torch.float32), torch.rsqrt(bn.running_var.to(torch.float32) + bn.eps)
+    return gate_block_fwd(x, mean, rstd, bn.weight, bn.bias, fc1_weight, fc1_bias, fc2_weight, fc2_bias, bn.training)[0]
+
+
+# ------------------------------------------------------------------------------------------------ concat
+def _concat_cols_impl(parts):
+    """cat(parts, dim=1) for 2-D fp32 row blocks in one launch (models/user_model.py:31, user_invariant_interest_model.py:81,88)."""
+    import ctypes
+    _require_gpu(*parts)
+    parts = [p if (p.dtype == torch.float32 and p.dim() == 2 and p.stride(1) == 1) else _f32c(p) for p in parts]
+    R = parts[0].shape[0]
+    total = sum(p.shape[1] for p in parts)
+    if len(parts) > 8 or any(p.shape[0] != R for p in parts):
+        return torch.cat(parts, dim=1)
+    out = torch.empty(R, _pad4(total), dtype=torch.float32, device=parts[0].device)
+    k = len(parts)
+    srcs = (ctypes.c_void_p * k)(*[p.data_ptr() for p in parts])
+    lds = (ctypes.c_long * k)(*[p.stride(0) if p.shape[0] > 1 else p.shape[1] for p in parts])
+    widths = (ctypes.c_int * k)(*[p.shape[1] for p in parts])
+    native.call("nrm_concat_cols", srcs, lds, widths, k, native.ptr(out), out.stride(0), R, native.stream_ptr())
+    return out[:, :total]
+
+
+concat_cols_op = _op("concat_cols", "(Tensor[] parts) -> Tensor", _concat_cols_impl,
+                     lambda parts: _padded_empty(parts[0], parts[0].shape[0], sum(p.shape[1] for p in parts)))
+
+
+def _concat_setup(ctx, inputs, output):
+    ctx.widths = [p.shape[1] for p in inputs[0]]
+
+
+def _concat_backward(ctx, g):
+    out, c = [], 0
+    for w in ctx.widths:
+        out.append(g[:, c:c + w])
+        c += w
+    return (out,)
+
+
+torch.library.register_autograd("nrm::concat_cols", _concat_backward, setup_context=_concat_setup, lib=_LIB)
+
+
+def concat_last(parts):
+    """torch.cat(parts, dim=-1) for tensors that agree in their leading dimensions, as one HIP launch."""
+    lead = parts[0].shape[:-1]
+    rows = 1
+    for d in lead:
+        rows *= d
+    if rows == 0 or len(parts) > 8:
+        return torch.cat(parts, dim=-1)
+    _require_gpu(*parts)
+    y = concat_cols_op([p.reshape(rows, p.shape[-1]) for p in parts])
+    return y.reshape(*lead, y.shape[-1]) if y.is_contiguous() else y.unflatten(0, tuple(lead))
 
 
 # ------------------------------------------------------------------------------------------------ pool
@@ -785,9 +914,15 @@ def _frontend_bwd_impl(dlab, x, behaviour, n_sub, P, cat_tab, sen_w, sen_b, type
     n_cat, e0, e1, n_type, e2, n_year, n_month, n_day, n_hour, e3 = dims
     dlab = _rows(dlab)
     dev = x.device
-    z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)      # noqa: E731
-    d_cat, d_sw, d_sb, d_type = z(n_cat, e0), z(e1, sen_w.shape[1]), z(e1), z(n_type, e2)
-    d_year, d_month, d_day, d_hour = z(n_year, e3), z(n_month, e3), z(n_day, e3), z(n_hour, e3)
+    # the eight gradient tables are carved out of ONE zero-initialised buffer (one fill launch instead of eight)
+    shapes = [(n_cat, e0), (e1, sen_w.shape[1]), (e1,), (n_type, e2), (n_year, e3), (n_month, e3), (n_day, e3), (n_hour, e3)]
+    sizes = [_pad4(int(torch.Size(sh).numel())) for sh in shapes]
+    arena = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    grads, o = [], 0
+    for sh, n in zip(shapes, sizes):
+        grads.append(arena[o:o + int(torch.Size(sh).numel())].view(sh))
+        o += n
+    d_cat, d_sw, d_sb, d_type, d_year, d_month, d_day, d_hour = grads
     native.call("nrm_frontend_bwd", native.ptr(x), 1 if x.dtype == torch.float64 else 0, x.shape[0], x.shape[1], P,
                 n_sub, 1 if behaviour else 0, native.ptr(dlab), dlab.stride(0), native.ptr(sen_w), native.ptr(sen_b),
                 n_cat, e0, e1, n_type, e2, n_year, n_month, n_day, n_hour, e3,
@@ -867,5 +1002,5 @@ adam_step = _op("adam_step", "(Tensor(a!) param, Tensor(b!) grad, Tensor(c!) exp
                 _adam_step_impl, lambda *a: None)
 
 OPS = ("pwattn_fwd", "pwattn_bwd", "linear_fwd", "linear_bwd", "mlp_gelu_fwd", "mlp_gelu_bwd", "batch_norm_stats", "batch_norm_apply",
-       "batch_norm_bwd",
+       "batch_norm_bwd", "gate_block_fwd", "gate_block_bwd", "concat_cols",
        "weighted_pool_fwd", "weighted_pool_bwd", "softmax_bce_loss", "frontend_fwd", "frontend_bwd", "row_auc", "adam_step")

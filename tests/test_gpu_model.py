@@ -245,10 +245,12 @@ def _fuzz_models(n=10, seed=77):
     return out
 
 
+@pytest.mark.parametrize("mma", ["f32", "bf16x3"])
 @pytest.mark.parametrize("emb,B,H,T,pad_h,pad_t", _fuzz_models())
-def test_random_models_match_oracle(lib, emb, B, H, T, pad_h, pad_t):
+def test_random_models_match_oracle(lib, emb, B, H, T, pad_h, pad_t, mma):
     """Seeded random model widths / batch shapes / padding: the whole step (forward, loss, every gradient) against the
-    oracle (which is pinned to the reference by the fixtures above)."""
+    oracle (which is pinned to the reference by the fixtures above) -- with fp32 MFMA and with the bf16x3 arithmetic of
+    BASELINE config 2, both held to the same gates."""
     from news_recommendation_model_amd import config, synth, trainer
     dims = config.Dims.for_emb(emb, 37)
     user_num = 3 * B
@@ -259,7 +261,7 @@ def test_random_models_match_oracle(lib, emb, B, H, T, pad_h, pad_t):
     tb_cpu = {k: torch.from_numpy(v) for k, v in batch.items() if isinstance(v, np.ndarray) and v.ndim > 0}
     tb_cpu = {k: (v.float() if v.is_floating_point() else v) for k, v in tb_cpu.items()}
     loss_o, r_o, g_o = orc.train_step(p, {"step": 0, "m": {}, "v": {}}, tb_cpu, lr=0.0)      # lr 0: values and gradients only
-    model = trainer.build_model(dims, user_num, sd, device="cuda").train()
+    model = trainer.build_model(dims, user_num, sd, device="cuda", attention_mma=mma).train()
     tb = trainer.batch_to_device(batch, "cuda")
     out = model(tb["x_history"], tb["x_target"], tb["x_global"])
     loss = model.loss(tb["user_id"], out, tb["label"])

@@ -71,6 +71,11 @@ def test_opcheck_dense_batchnorm_loss_frontend(lib):
     mean, rstd = torch.ops.nrm.batch_norm_stats(x.detach(), rm, rv, 0.1, 1e-5)
     gamma, beta = r(24).requires_grad_(True), r(24).requires_grad_(True)
     _opcheck(torch.ops.nrm.batch_norm_apply.default, (x, mean, rstd, gamma, beta, True))
+    # BatchNorm -> gate MLP -> product as one node, and the one-launch concat
+    wg1, bg1 = (0.2 * r(6, 24)).requires_grad_(True), r(6).requires_grad_(True)
+    wg2, bg2 = (0.2 * r(24, 6)).requires_grad_(True), r(24).requires_grad_(True)
+    _opcheck(torch.ops.nrm.gate_block_fwd.default, (x, mean, rstd, gamma, beta, wg1, bg1, wg2, bg2, True))
+    _opcheck(torch.ops.nrm.concat_cols.default, ([x, r(37, 3).requires_grad_(True), r(37, 10)[:, :7].requires_grad_(True)],))
     # loss
     out = r(6, 9).requires_grad_(True)
     delta = (0.1 * r(5)).requires_grad_(True)
@@ -135,3 +140,47 @@ def test_modules_pickle_into_a_child_process_that_runs_the_ops(lib, tmp_path):
     assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-2000:]
     got = np.load(tmp_path / "out.npy")
     assert np.abs(got - fx["r"]).max() / np.abs(fx["r"]).max() < 1e-3
+
+
+def test_gate_block_and_concat_match_the_separate_ops(lib):
+    """ops.gate_block (BatchNorm -> gate MLP -> product, one autograd node; the two gradients of the rows are joined inside the
+    BatchNorm backward kernel) against the same computation from the separate ops and from plain PyTorch in fp64; and
+    ops.concat_last against torch.cat."""
+    from news_recommendation_model_amd import ops
+    torch.manual_seed(3)
+    R, N = 53, 40
+    x0 = torch.randn(R, N, device="cuda")
+    w1, b1 = 0.2 * torch.randn(N // 4, N, device="cuda"), 0.1 * torch.randn(N // 4, device="cuda")
+    w2, b2 = 0.2 * torch.randn(N, N // 4, device="cuda"), 0.1 * torch.randn(N, device="cuda")
+    gy = torch.randn(R, N, device="cuda")
+    results = []
+    for mode in ("fused", "separate", "torch64"):
+        bn = torch.nn.BatchNorm1d(N).cuda().train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, N)); bn.bias.copy_(torch.linspace(-0.2, 0.2, N))
+        dt = torch.float64 if mode == "torch64" else torch.float32
+        if mode == "torch64":
+            bn = bn.double()
+        x = x0.to(dt).clone().requires_grad_(True)
+        ps = [t.to(dt).clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+        if mode == "fused":
+            y = ops.gate_block(x, bn, *ps)
+        elif mode == "separate":
+            y = ops.mlp_gelu(ops.batch_norm(x, bn), *ps, mul=x)
+        else:
+            c = bn(x)
+            y = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(c, ps[0], ps[1])), ps[2], ps[3]) * x
+        y.backward(gy.to(dt))
+        results.append([y.detach().double(), x.grad.double(), bn.weight.grad.double(), bn.bias.grad.double(), bn.running_var.double()]
+                       + [p.grad.double() for p in ps])
+    for a, b, c in zip(*results):
+        assert torch.allclose(a, c, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(b, c, rtol=1e-4, atol=1e-5)
+    parts = [torch.randn(4, 6, 10, device="cuda", requires_grad=True), torch.randn(4, 6, 3, device="cuda", requires_grad=True),
+             torch.randn(4, 6, 8, device="cuda")[..., :5].requires_grad_(True)]
+    got = ops.concat_last(parts)
+    want = torch.cat([p.detach() for p in parts], dim=-1)
+    assert torch.equal(got, want)
+    g = torch.randn_like(want)
+    got.backward(g)
+    assert torch.equal(parts[1].grad, g[..., 10:13]) and torch.equal(parts[2].grad, g[..., 13:18])
