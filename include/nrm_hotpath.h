@@ -85,14 +85,26 @@ long nrm_gemm_packed_floats(int nrows, int ncols);
  * nrm_gemm_nt, columns its reduction index.  Linear.forward: (W[N,K], K, 1, N, K); dX = dY W: (W, 1, K, K, N) */
 int nrm_gemm_pack(const float* src, long row_stride, long col_stride, int nrows, int ncols, float* packed,
                   nrm_stream_t stream);
+/* the same for n matrices in ONE launch (descs is a HOST array, copied into the kernel arguments): what a training loop
+ * calls once per optimizer step for every Linear in both GEMM orientations instead of once per GEMM.  With src2 != NULL the
+ * packed matrix is src + sign2 * src2 (same strides): the attention's side projections W_h - W_d and W_t + W_d
+ * (reference models/attention_model.py:81-86, re-associated) are formed here. */
+typedef struct {
+    const float* src; const float* src2; float sign2;
+    long row_stride, col_stride; int nrows, ncols;
+    float* packed;           /* nrm_gemm_packed_floats(nrows, ncols) floats */
+} nrm_pack_desc;
+int nrm_gemm_pack_multi(const nrm_pack_desc* descs, int n, nrm_stream_t stream);
 /* y[M, N] (ld ldy) = epilogue( x[M, K] (ld ldx) * packed^T ), bias [N] or NULL; m [M, N] (ld ldm) for NRM_EPI_MUL */
 int nrm_gemm_nt(const float* x, int ldx, int M, const float* packed, int N, int K, const float* bias,
                 float* y, int ldy, float* z, int ldz, const float* m, int ldm, int epilogue, nrm_stream_t stream);
 /* C[i,j] = sum_r A[r,i] B[r,j]  (dW = dY^T X): writes nsplit TRANSPOSED partial slabs ws[s][j][ldws] and, if
  * colsum != NULL, colsum[s][i] = sum_r A[r,i] (the bias gradient); sum over s.  ldws % 4 == 0, ldws >= ncols_i */
 int nrm_gemm_tn_nsplit(int ncols_i, int ncols_j, int R);
+/* zero_out (optional, 16-byte aligned): zero_n floats there are set to 0 by the same launch -- the gradient buffer that
+ * nrm_slab_reduce will then add the slabs to */
 int nrm_gemm_tn(const float* A, int lda, int ncols_i, const float* B, int ldb, int ncols_j, int R,
-                float* ws, int ldws, float* colsum, nrm_stream_t stream);
+                float* ws, int ldws, float* colsum, float* zero_out, long zero_n, nrm_stream_t stream);
 
 /* the split slabs ws[s][j][ldws] of nrm_gemm_tn / nrm_pwattn_bwd_contract summed over s and ADDED (float atomics; the
  * caller zero-initialises, or accumulates on purpose) where the gradient lives:

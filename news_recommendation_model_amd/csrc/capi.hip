@@ -173,6 +173,27 @@ int nrm_gemm_pack(const float* src, long row_stride, long col_stride, int nrows,
                                            (hipStream_t)stream), "pack_rows");
 }
 
+int nrm_gemm_pack_multi(const nrm_pack_desc* descs, int n, nrm_stream_t stream) {
+    if (n < 0 || (n > 0 && !descs)) return fail(NRM_EINVAL, "nrm_gemm_pack_multi: bad argument");
+    for (int lo = 0; lo < n; lo += nrm::PACK_MAX) {
+        const int m = n - lo < nrm::PACK_MAX ? n - lo : nrm::PACK_MAX;
+        nrm::PackTable tab = {};
+        long mx = 0;
+        for (int i = 0; i < m; ++i) {
+            const nrm_pack_desc& d = descs[lo + i];
+            if (!d.src || !d.packed || d.nrows <= 0 || d.ncols <= 0) return fail(NRM_EINVAL, "nrm_gemm_pack_multi: entry %d is malformed", lo + i);
+            const nrm::GemmNtPlan pl = nrm::gemm_nt_plan(d.nrows);
+            nrm::PackEntry& e = tab.e[i];
+            e.src = d.src; e.src2 = d.src2; e.dst = d.packed; e.rs = d.row_stride; e.cs = d.col_stride;
+            e.nrows = d.nrows; e.ncols = d.ncols; e.rows = pl.rows; e.kchunks = (d.ncols + 15) / 16; e.sign2 = d.sign2;
+            const long total = (long)e.kchunks * e.rows * 16;
+            if (total > mx) mx = total;
+        }
+        if (int rc = check_hip(nrm::pack_rows_multi_launch(tab, m, mx, (hipStream_t)stream), "pack_rows_multi")) return rc;
+    }
+    return NRM_OK;
+}
+
 int nrm_gemm_nt(const float* x, int ldx, int M, const float* packed, int N, int K, const float* bias,
                 float* y, int ldy, float* z, int ldz, const float* m, int ldm, int epilogue, nrm_stream_t stream) {
     if (!x || !packed || !y) return fail(NRM_EINVAL, "nrm_gemm_nt: null pointer");
@@ -206,7 +227,7 @@ int nrm_gemm_tn_nsplit(int ncols_i, int ncols_j, int R) {
 }
 
 int nrm_gemm_tn(const float* A, int lda, int ncols_i, const float* B, int ldb, int ncols_j, int R,
-                float* ws, int ldws, float* colsum, nrm_stream_t stream) {
+                float* ws, int ldws, float* colsum, float* zero_out, long zero_n, nrm_stream_t stream) {
     if (!A || !B || !ws) return fail(NRM_EINVAL, "nrm_gemm_tn: null pointer");
     if (ncols_i <= 0 || ncols_j <= 0 || R <= 0 || lda < ncols_i || ldb < ncols_j)
         return fail(NRM_EINVAL, "nrm_gemm_tn: ncols_i=%d ncols_j=%d R=%d lda=%d ldb=%d", ncols_i, ncols_j, R, lda, ldb);
@@ -215,7 +236,9 @@ int nrm_gemm_tn(const float* A, int lda, int ncols_i, const float* B, int ldb, i
     if ((long)pl.rps * (lda > ldb ? lda : ldb) * 4 >= (1L << 31)) return fail(NRM_EINVAL, "nrm_gemm_tn: split too large");
     nrm::GemmTnParams p = {};
     p.A = A; p.lda = lda; p.acols = lda; p.B = B; p.ldb = ldb; p.bcols = ldb;
+    if (zero_out && (zero_n < 0 || !al16(zero_out))) return fail(NRM_EINVAL, "nrm_gemm_tn: zero_out must be 16-byte aligned, zero_n >= 0");
     p.ws = ws; p.ldws = ldws; p.colsum = colsum; p.R = R; p.ncols_j = ncols_j;
+    p.zero_out = zero_out; p.zero_n = zero_out ? zero_n : 0;
     return check_hip(nrm::gemm_tn_launch(p, pl, (hipStream_t)stream), "gemm_tn");
 }
 

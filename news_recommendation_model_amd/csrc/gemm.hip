@@ -33,6 +33,39 @@ __global__ void pack_rows_kernel(const float* __restrict__ src, long rs, long cs
     }
 }
 
+// Several weight matrices in ONE launch (blockIdx.y = matrix; the table travels in the kernel arguments): every Linear of
+// the model in both GEMM orientations, re-packed once per optimizer step instead of once per GEMM call (24 launches per
+// step).  An entry may be the sum / difference of two sources: the attention's side projections use W_h - W_d and
+// W_t + W_d (pwattn_fwd.hip), formed here instead of by separate elementwise launches.
+__global__ __launch_bounds__(256) void pack_rows_multi_kernel(const PackTable tab) {
+    const PackEntry e = tab.e[blockIdx.y];
+    const long total = (long)e.kchunks * e.rows * 16;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 15);
+        const long rc = i >> 4;
+        const int row = (int)(rc % e.rows);
+        const int c = (int)(rc / e.rows);
+        const int slot = (j >> 2) ^ swz4(row);
+        const int col = c * 16 + 4 * slot + (j & 3);
+        float v = 0.0f;
+        if (row < e.nrows && col < e.ncols) {
+            const long o = row * e.rs + col * e.cs;
+            v = e.src[o];
+            if (e.src2) v = fmaf(e.sign2, e.src2[o], v);
+        }
+        e.dst[i] = v;
+    }
+}
+
+hipError_t pack_rows_multi_launch(const PackTable& tab, int n, long max_total, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    long bx = (max_total + 255) / 256;
+    if (bx > 128) bx = 128;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(pack_rows_multi_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, tab);
+    return hipGetLastError();
+}
+
 hipError_t pack_rows_launch(const float* src, long rs, long cs, int nrows, int ncols, int rows, int kchunks,
                             float* packed, hipStream_t st) {
     const long total = (long)kchunks * rows * 16;
@@ -230,6 +263,14 @@ __global__ __launch_bounds__(256, KT == 4 ? 4 : 3) void gemm_tn_kernel(const Gem
     const int bx = logical % gridDim.x, by = logical / gridDim.x;
     const int ti = bx % p.nti, tj = bx / p.nti;
     const int i0 = ti * (KT * 16), j0 = tj * (DT * 16);
+    // the gradient this GEMM's slabs will be ADDED to by the slab reduction is zeroed here, on the side (its own fill
+    // launch otherwise: 12 per step)
+    if (p.zero_out) {
+        const long n4 = p.zero_n >> 2;
+        const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (long i = (long)lin * 256 + tid; i < n4; i += (long)nblk * 256) reinterpret_cast<f32x4*>(p.zero_out)[i] = z4;
+        for (long i = (n4 << 2) + (long)lin * 256 + tid; i < p.zero_n; i += (long)nblk * 256) p.zero_out[i] = 0.f;
+    }
     const int split = by * 4 + wave;
     if (split >= p.nsplit) return;
     const int r_lo = split * p.rps;

@@ -22,11 +22,17 @@ hipError_t gemm_nt_launch(const GemmNtParams& p, const GemmNtPlan& pl, int epi, 
 hipError_t pack_rows_launch(const float* src, long rs, long cs, int nrows, int ncols, int rows, int kchunks,
                             float* packed, hipStream_t st);
 
+constexpr int PACK_MAX = 40;
+struct PackEntry { const float* src; const float* src2; float* dst; long rs, cs; int nrows, ncols, rows, kchunks; float sign2; };
+struct PackTable { PackEntry e[PACK_MAX]; };          // 40 x 64 B of kernel arguments
+hipError_t pack_rows_multi_launch(const PackTable& tab, int n, long max_total, hipStream_t st);
+
 struct GemmTnParams {
     const float* A; int lda, acols;       // [R, lda]   i-columns
     const float* B; int ldb, bcols;       // [R, ldb]   j-columns
     float* ws; int ldws;                  // [nsplit][ncols_j][ldws]   C^T partial slabs
     float* colsum;                        // [nsplit][ldws] column sums of A, or nullptr
+    float* zero_out; long zero_n;         // optional: zero_n floats at zero_out (16-byte aligned) are set to 0 by this launch
     int R, ncols_j;
     int nti, nsplit, rps;                 // filled by gemm_tn_launch from the plan
 };

@@ -34,7 +34,8 @@ SIGNATURES = {
     "nrm_bn_finalize": (_c_i, [_c_i, _c_fp, _c_fp, _c_fp, _c_i, _c_i, ctypes.c_float, ctypes.c_float, _c_fp]),
     "nrm_mul_bwd": (_c_i, [_c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_fp]),
     "nrm_gemm_tn_nsplit": (_c_i, [_c_i, _c_i, _c_i]),
-    "nrm_gemm_tn": (_c_i, [_c_fp, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_fp]),
+    "nrm_gemm_tn": (_c_i, [_c_fp, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_fp, _c_l, _c_fp]),
+    "nrm_gemm_pack_multi": (_c_i, [_c_fp, _c_i, _c_fp]),
     "nrm_colreduce": (_c_i, [_c_i] + [_c_fp] * 6 + [_c_i] * 3 + [_c_fp]),
     "nrm_bn_apply": (_c_i, [_c_fp] * 6 + [_c_i] * 3 + [_c_fp]),
     "nrm_bn_backward": (_c_i, [_c_fp] * 9 + [_c_i] * 4 + [_c_fp]),
@@ -52,6 +53,15 @@ SIGNATURES = {
     "nrm_frontend_bwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,  _c_fp, _c_i, _c_fp, _c_fp]
                          + [_c_i] * 10 + [_c_fp] * 8 + [_c_fp]),
 }
+
+
+
+class PackDesc(ctypes.Structure):
+    """nrm_pack_desc of include/nrm_hotpath.h"""
+    _fields_ = [("src", ctypes.c_void_p), ("src2", ctypes.c_void_p), ("sign2", ctypes.c_float),
+                ("row_stride", ctypes.c_long), ("col_stride", ctypes.c_long), ("nrows", ctypes.c_int), ("ncols", ctypes.c_int),
+                ("packed", ctypes.c_void_p)]
+
 
 _lib = None
 _lock = threading.Lock()

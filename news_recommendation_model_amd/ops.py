@@ -89,13 +89,94 @@ def _padded_empty(like, rows, cols):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM plumbing
-def _gemm_nt(x, w_src, row_stride, col_stride, n_out, k_red, bias, epilogue, z=None, m=None):
-    """y[M, n_out] = epilogue(x[M, k_red] * Wlogical^T), Wlogical[r, c] = w_src[r*row_stride + c*col_stride]."""
+class _PackedWeights:
+    """The GEMM kernels stream their weight operand from a packed image (nrm_gemm_pack).  Weights change once per optimizer
+    step, so the images of PERSISTENT weights (model parameters) are kept here, keyed by source pointer + layout, and
+
+    * re-packed lazily, one launch per image, whenever the parameter's autograd version counter has moved
+      (``torch.optim`` steps, ``load_state_dict``) -- what every call did before;
+    * re-packed ALL TOGETHER by one launch (``nrm_gemm_pack_multi``) when ``repack_persistent()`` is called -- which
+      ``trainer.FlatAdam.step()`` does right after its Adam launch (it updates the weights through a raw pointer, so it also
+      bumps ``epoch`` to invalidate whatever is not refreshed);
+    * simply re-used while nothing changed (inference).
+    Temporaries (``owner=None``) are packed per call into a fresh buffer and never cached."""
+
+    def __init__(self):
+        self.entries = {}
+        self.epoch = 0
+
+
+class _PackEntry:
+    __slots__ = ("buf", "owner", "owner_ptr", "version", "epoch", "spec")
+
+
+_packs = _PackedWeights()
+
+
+def _pack_desc(src, rs, cs, nrows, ncols, src2, sign2, buf):
+    return native.PackDesc(src.data_ptr(), src2.data_ptr() if src2 is not None else None, float(sign2), int(rs), int(cs),
+                           int(nrows), int(ncols), buf.data_ptr())
+
+
+def _pack(src, rs, cs, nrows, ncols, src2=None, sign2=0.0, owner=None):
+    """Packed image of the logical [nrows x ncols] matrix src[r*rs + c*cs] (+ sign2 * src2[same]); see _PackedWeights."""
+    import weakref
     lib = native.load()
+    if owner is None:
+        buf = torch.empty(lib.nrm_gemm_packed_floats(nrows, ncols), dtype=torch.float32, device=src.device)
+        d = _pack_desc(src, rs, cs, nrows, ncols, src2, sign2, buf)
+        native.call("nrm_gemm_pack_multi", ctypes_ref(d), 1, native.stream_ptr())
+        return buf
+    key = (src.data_ptr(), int(rs), int(cs), int(nrows), int(ncols), src2.data_ptr() if src2 is not None else 0, float(sign2))
+    ent = _packs.entries.get(key)
+    if ent is not None and (ent.owner() is not owner or ent.owner_ptr != owner.data_ptr()):
+        ent = None                                                   # the address now belongs to another tensor
+    if ent is not None and ent.version == owner._version and ent.epoch == _packs.epoch:
+        return ent.buf
+    if ent is None:
+        ent = _PackEntry()
+        ent.buf = torch.empty(lib.nrm_gemm_packed_floats(nrows, ncols), dtype=torch.float32, device=src.device)
+        ent.owner, ent.owner_ptr = weakref.ref(owner), owner.data_ptr()
+        ent.spec = (src, rs, cs, nrows, ncols, src2, sign2)          # views keep the parameter's storage alive
+        _packs.entries[key] = ent
+    d = _pack_desc(src, rs, cs, nrows, ncols, src2, sign2, ent.buf)
+    native.call("nrm_gemm_pack_multi", ctypes_ref(d), 1, native.stream_ptr())
+    ent.version, ent.epoch = owner._version, _packs.epoch
+    return ent.buf
+
+
+def ctypes_ref(desc_or_array):
+    import ctypes
+    return ctypes.cast(ctypes.pointer(desc_or_array), ctypes.c_void_p)
+
+
+def repack_persistent(device=None):
+    """Every cached weight image refreshed from its (just updated) parameter by ONE launch; entries whose parameter is gone or
+    has been re-seated are dropped.  Called by trainer.FlatAdam.step(); harmless to call at any time."""
+    _packs.epoch += 1
+    live = []
+    for key, ent in list(_packs.entries.items()):
+        owner = ent.owner()
+        if owner is None or owner.data_ptr() != ent.owner_ptr or (device is not None and ent.buf.device != torch.device(device)):
+            if owner is None or owner.data_ptr() != ent.owner_ptr:
+                del _packs.entries[key]
+            continue
+        live.append((ent, owner))
+    if not live:
+        return 0
+    arr = (native.PackDesc * len(live))(*[_pack_desc(*ent.spec, ent.buf) for ent, _ in live])
+    native.call("nrm_gemm_pack_multi", ctypes_ref(arr), len(live), native.stream_ptr())
+    for ent, owner in live:
+        ent.version, ent.epoch = owner._version, _packs.epoch
+    return len(live)
+
+
+def _gemm_nt(x, w_src, row_stride, col_stride, n_out, k_red, bias, epilogue, z=None, m=None, src2=None, sign2=0.0, owner=None):
+    """y[M, n_out] = epilogue(x[M, k_red] * Wlogical^T), Wlogical[r, c] = w_src[r*row_stride + c*col_stride]
+    (+ sign2 * src2[same]); ``owner`` = the parameter w_src is a view of (its packed image is then cached)."""
     st = native.stream_ptr()
     M = x.shape[0]
-    packed = torch.empty(lib.nrm_gemm_packed_floats(n_out, k_red), dtype=torch.float32, device=x.device)
-    native.call("nrm_gemm_pack", native.ptr(w_src), row_stride, col_stride, n_out, k_red, native.ptr(packed), st)
+    packed = _pack(w_src, row_stride, col_stride, n_out, k_red, src2, sign2, owner)
     ldy = _pad4(n_out)
     y = torch.empty(M, ldy, dtype=torch.float32, device=x.device)
     if epilogue in (EPI_GELU, EPI_MUL):
@@ -107,8 +188,9 @@ def _gemm_nt(x, w_src, row_stride, col_stride, n_out, k_red, bias, epilogue, z=N
     return y[:, :n_out], (z[:, :n_out] if epilogue in (EPI_GELU, EPI_MUL) else None)
 
 
-def _gemm_tn_slabs(a, b, want_colsum):
-    """Partial slabs of (sum_r a[r,i] b[r,j]): ws[s][j][ldws] (TRANSPOSED) and the per-split column sums of a."""
+def _gemm_tn_slabs(a, b, want_colsum, zero_out=None):
+    """Partial slabs of (sum_r a[r,i] b[r,j]): ws[s][j][ldws] (TRANSPOSED) and the per-split column sums of a; ``zero_out``
+    (the buffer the slab reduction will add to) is zeroed by the same launch."""
     lib = native.load()
     R, ni = a.shape
     nj = b.shape[1]
@@ -117,7 +199,9 @@ def _gemm_tn_slabs(a, b, want_colsum):
     ws = torch.empty(nsplit, nj, ldws, dtype=torch.float32, device=a.device)
     cs = torch.empty(nsplit, ldws, dtype=torch.float32, device=a.device) if want_colsum else None
     native.call("nrm_gemm_tn", native.ptr(a), a.stride(0), ni, native.ptr(b), b.stride(0), nj, R,
-                native.ptr(ws), ldws, native.ptr(cs) if cs is not None else None, native.stream_ptr())
+                native.ptr(ws), ldws, native.ptr(cs) if cs is not None else None,
+                native.ptr(zero_out) if zero_out is not None else None, zero_out.numel() if zero_out is not None else 0,
+                native.stream_ptr())
     return ws, cs, nsplit, ldws
 
 
@@ -134,8 +218,8 @@ def _gemm_tn(a, b, want_colsum):
     """(sum_r a[r,i] b[r,j]) as a contiguous [ni, nj], and optionally sum_r a[r,i]: the split-M GEMM plus ONE
     reduce+transpose launch that writes the gradient in place (no ATen sum/t/contiguous)."""
     ni, nj = a.shape[1], b.shape[1]
-    ws, cs, nsplit, ldws = _gemm_tn_slabs(a, b, want_colsum)
-    c = torch.zeros(ni, nj, dtype=torch.float32, device=a.device)
+    c = torch.empty(ni, nj, dtype=torch.float32, device=a.device)      # zeroed by the GEMM launch itself
+    ws, cs, nsplit, ldws = _gemm_tn_slabs(a, b, want_colsum, zero_out=c)
     colsum = torch.empty(ni, dtype=torch.float32, device=a.device) if want_colsum else None
     _slab_reduce(ws, nsplit, nj, ldws, ni, c, nj, 1, vec=cs, vec_out=colsum)
     return c, colsum
@@ -162,13 +246,14 @@ def _pwattn_fwd_impl(t, h, w1, b1, w2, b2, save_z, mma):
     if h.shape[0] != B or h.shape[2] != D or tuple(w1.shape) != (D, 4 * D) or D % 4:
         raise RuntimeError(f"pointwise attention: target {tuple(t.shape)}, history {tuple(h.shape)}, "
                            f"fc1 {tuple(w1.shape)} do not agree (feature width must be a multiple of 4)")
+    w1_arg = w1
     t, h, w1, b1 = _f32c(t), _f32c(h), _f32c(w1), _f32c(b1)
     w2v, b2 = _f32c(w2).reshape(-1), _f32c(b2).reshape(-1)
+    # side projections u = h (W_h - W_d)^T + b1, v = t (W_t + W_d)^T: the difference / sum is formed by the pack kernel
+    own = w1 if w1 is w1_arg else None
     w_h, w_t, w_d = w1[:, :D], w1[:, D:2 * D], w1[:, 2 * D:3 * D]
-    a_h = (w_h - w_d).contiguous()
-    a_t = (w_t + w_d).contiguous()
-    u, _ = _gemm_nt(h.reshape(B * H, D), a_h, D, 1, D, D, b1, EPI_BIAS)       # [B*H, D]
-    v, _ = _gemm_nt(t.reshape(B * T, D), a_t, D, 1, D, D, None, EPI_BIAS)     # [B*T, D]
+    u, _ = _gemm_nt(h.reshape(B * H, D), w_h, 4 * D, 1, D, D, b1, EPI_BIAS, src2=w_d, sign2=-1.0, owner=own)     # [B*H, D]
+    v, _ = _gemm_nt(t.reshape(B * T, D), w_t, 4 * D, 1, D, D, None, EPI_BIAS, src2=w_d, sign2=1.0, owner=own)   # [B*T, D]
     st = native.stream_ptr()
     packed = torch.empty(native.load().nrm_pwattn_packed_floats(D), dtype=torch.float32, device=t.device)
     native.call("nrm_pwattn_pack_wp", native.ptr(w1), 4 * D, D, mma, native.ptr(packed), st)
@@ -198,7 +283,9 @@ def _pwattn_bwd_impl(ds, t, h, w1, w2, z, mma):
     B, T, D = t.shape
     H = h.shape[1]
     st = native.stream_ptr()
+    w1_arg = w1
     t, h, w1, ds = _f32c(t), _f32c(h), _f32c(w1), _f32c(ds)
+    own = w1 if w1 is w1_arg else None
     w2v = _f32c(w2).reshape(-1)
     dev = t.device
     dw2 = torch.zeros(D, dtype=torch.float32, device=dev)
@@ -210,19 +297,18 @@ def _pwattn_bwd_impl(ds, t, h, w1, w2, z, mma):
     dz = z
     db2 = ds.sum().reshape(1)
     w_h, w_t, w_d = w1[:, :D], w1[:, D:2 * D], w1[:, 2 * D:3 * D]
-    a_h = (w_h - w_d).contiguous()
-    a_t = (w_t + w_d).contiguous()
     du2, dv2 = du.reshape(B * H, D), dv.reshape(B * T, D)
     # fc1 gradient [D, 4D] = [da_h | da_t | da_t - da_h | dW_p]: every block is written in place by a slab reduction
-    dw1 = torch.zeros(D, 4 * D, dtype=torch.float32, device=dev)
+    dw1 = torch.empty(D, 4 * D, dtype=torch.float32, device=dev)                    # zeroed by the first GEMM launch below
     db1 = torch.empty(D, dtype=torch.float32, device=dev)
-    ws, cs, ns, ldws = _gemm_tn_slabs(du2, h.reshape(B * H, D), True)               # du^T h, db1 = column sums of du
+    ws, cs, ns, ldws = _gemm_tn_slabs(du2, h.reshape(B * H, D), True, zero_out=dw1)  # du^T h, db1 = column sums of du
     _slab_reduce(ws, ns, D, ldws, D, dw1, 4 * D, 1, out2=dw1[:, 2 * D:], out2_is=4 * D, out2_js=1, sign2=-1.0,
                  vec=cs, vec_out=db1)
     ws, _, ns, ldws = _gemm_tn_slabs(dv2, t.reshape(B * T, D), False)
     _slab_reduce(ws, ns, D, ldws, D, dw1[:, D:], 4 * D, 1, out2=dw1[:, 2 * D:], out2_is=4 * D, out2_js=1, sign2=1.0)
-    dh = _gemm_nt(du2, a_h, 1, D, D, D, None, EPI_BIAS)[0].reshape(B, H, D)        # du A_h   (D % 4 == 0: contiguous)
-    dt = _gemm_nt(dv2, a_t, 1, D, D, D, None, EPI_BIAS)[0].reshape(B, T, D)        # dv A_t
+    # du (W_h - W_d), dv (W_t + W_d): the transposed orientation of the same two combinations   (D % 4 == 0: contiguous results)
+    dh = _gemm_nt(du2, w_h, 1, 4 * D, D, D, None, EPI_BIAS, src2=w_d, sign2=-1.0, owner=own)[0].reshape(B, H, D)
+    dt = _gemm_nt(dv2, w_t, 1, 4 * D, D, D, None, EPI_BIAS, src2=w_d, sign2=1.0, owner=own)[0].reshape(B, T, D)
     nsplit = native.load().nrm_pwattn_bwd_nsplit(B, T, H, D)
     wsp = torch.empty(nsplit, D, D, dtype=torch.float32, device=dev)
     wp = w1[:, 3 * D:]                                   # view, row stride 4D
@@ -313,7 +399,7 @@ def _linear_fwd_impl(x, weight, bias, gelu):
     if x.shape[1] != K:
         raise RuntimeError(f"linear: input has {x.shape[1]} features, weight expects {K}")
     b = _f32c(bias) if bias is not None else None
-    y, z = _gemm_nt(x, w, K, 1, N, K, b, EPI_GELU if gelu else EPI_BIAS)
+    y, z = _gemm_nt(x, w, K, 1, N, K, b, EPI_GELU if gelu else EPI_BIAS, owner=w if w is weight else None)
     return y, (z if gelu else y.new_empty((0,)))
 
 
@@ -339,7 +425,7 @@ def _linear_bwd_impl(dy, x, weight, z, has_bias, need_dx, need_dw):
     if need_dw:
         dw, db = _gemm_tn(dy, x, has_bias)                  # dW[n,k] = sum_m dy[m,n] x[m,k]
     if need_dx:
-        dx, _ = _gemm_nt(dy, w, 1, K, K, N, None, EPI_BIAS)  # dX = dY W : rows of the packed operand = k
+        dx, _ = _gemm_nt(dy, w, 1, K, K, N, None, EPI_BIAS, owner=w if w is weight else None)  # dX = dY W : rows of the packed operand = k
     e = lambda: torch.empty((0,), dtype=torch.float32, device=dev)      # noqa: E731
     return (dx if dx is not None else e()), (dw if dw is not None else e()), (db if db is not None else e())
 
@@ -391,20 +477,22 @@ def _mlp_gelu_fwd_impl(x, w1, b1, w2, b2, mul):
     user_model.py:33 -- the product with the raw concat fused into the second."""
     _require_gpu(x, w1, w2, mul)
     x = _rows(x)
+    o1, o2 = w1, w2
     w1, w2 = _f32c(w1), _f32c(w2)
+    o1, o2 = (w1 if w1 is o1 else None), (w2 if w2 is o2 else None)
     N1, K1 = w1.shape
     N2, K2 = w2.shape
     if x.shape[1] != K1 or K2 != N1:
         raise RuntimeError(f"mlp: input has {x.shape[1]} features, fc1 expects {K1}, fc2 expects {K2} hidden")
-    hidden, z = _gemm_nt(x, w1, K1, 1, N1, K1, _f32c(b1) if b1 is not None else None, EPI_GELU)
+    hidden, z = _gemm_nt(x, w1, K1, 1, N1, K1, _f32c(b1) if b1 is not None else None, EPI_GELU, owner=o1)
     if mul is None:
-        y, _ = _gemm_nt(hidden, w2, K2, 1, N2, K2, _f32c(b2) if b2 is not None else None, EPI_BIAS)
+        y, _ = _gemm_nt(hidden, w2, K2, 1, N2, K2, _f32c(b2) if b2 is not None else None, EPI_BIAS, owner=o2)
         pre = y.new_empty((0,))
     else:
         m = _rows(mul)
         if tuple(m.shape) != (x.shape[0], N2):
             raise RuntimeError(f"mlp: multiplier {tuple(m.shape)} does not match the output {(x.shape[0], N2)}")
-        y, pre = _gemm_nt(hidden, w2, K2, 1, N2, K2, _f32c(b2) if b2 is not None else None, EPI_MUL, m=m)
+        y, pre = _gemm_nt(hidden, w2, K2, 1, N2, K2, _f32c(b2) if b2 is not None else None, EPI_MUL, m=m, owner=o2)
     return y, hidden, z, pre
 
 
@@ -423,7 +511,9 @@ def _mlp_gelu_bwd_impl(dy, x, w1, w2, hidden, z, pre, mul, has_b1, has_b2, need_
     (NRM_EPI_DGELU), then dW1/db1 and dX -- no elementwise pass over the hidden activations in either direction.  With a
     multiplier (the gate), dY is first split by one fused kernel into d(fc2 output) = dY * mul and d(mul) = dY * fc2 output."""
     _require_gpu(dy, x, w1, w2)
+    o1, o2 = w1, w2
     x, w1, w2 = _rows(x), _f32c(w1), _f32c(w2)
+    o1, o2 = (w1 if w1 is o1 else None), (w2 if w2 is o2 else None)
     N1, K1 = w1.shape
     N2, K2 = w2.shape
     dy = _rows(dy)
@@ -443,10 +533,10 @@ def _mlp_gelu_bwd_impl(dy, x, w1, w2, hidden, z, pre, mul, has_b1, has_b2, need_
             dy, dmul = _rows(dy * m), dy * pre
     dw2, db2 = _gemm_tn(dy, hidden, has_b2)                          # dW2[n,k] = sum_m dy[m,n] hidden[m,k]
     # d(pre-activation of fc1) = (dY W2) * gelu'(z): epilogue 2 reads z and writes the product
-    dz, _ = _gemm_nt(dy, w2, 1, K2, K2, N2, None, EPI_DGELU, z=z)
+    dz, _ = _gemm_nt(dy, w2, 1, K2, K2, N2, None, EPI_DGELU, z=z, owner=o2)
     dw1, db1 = _gemm_tn(dz, x, has_b1)
     e = lambda: torch.empty((0,), dtype=torch.float32, device=dev)      # noqa: E731
-    dx = _gemm_nt(dz, w1, 1, K1, K1, N1, None, EPI_BIAS)[0] if need_dx else e()
+    dx = _gemm_nt(dz, w1, 1, K1, K1, N1, None, EPI_BIAS, owner=o1)[0] if need_dx else e()
     return dx, dw1, (db1 if has_b1 else e()), dw2, (db2 if has_b2 else e()), dmul
 
 

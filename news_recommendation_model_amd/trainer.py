@@ -129,6 +129,9 @@ class FlatAdam:
         ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.state,
                       float(self.param_groups[0]["lr"]), float(self.betas[0]), float(self.betas[1]), float(self.eps),
                       float(self.weight_decay), bool(zero_grad))          # torch.ops.nrm.adam_step -> nrm_adam_step_dev
+        # the weights moved (through a raw pointer: no autograd version bump): every cached packed GEMM operand is
+        # refreshed by ONE launch instead of one per GEMM call of the next step
+        ops.repack_persistent()
         self._collected = False
 
     def zero_grad(self, set_to_none=False):
