@@ -171,6 +171,14 @@ def repack_persistent(device=None):
     return len(live)
 
 
+def invalidate_packed_weights():
+    """Forget every cached packed weight image.  Needed only after writing to a parameter in a way autograd's version counter
+    does not see (``param.data.copy_(...)``, a raw-pointer update): in-place ops on the parameter itself, ``load_state_dict``,
+    ``.to()`` and ``torch.optim`` steps are noticed on their own, ``trainer.FlatAdam`` refreshes the images itself."""
+    _packs.entries.clear()
+    _packs.epoch += 1
+
+
 def _gemm_nt(x, w_src, row_stride, col_stride, n_out, k_red, bias, epilogue, z=None, m=None, src2=None, sign2=0.0, owner=None):
     """y[M, n_out] = epilogue(x[M, k_red] * Wlogical^T), Wlogical[r, c] = w_src[r*row_stride + c*col_stride]
     (+ sign2 * src2[same]); ``owner`` = the parameter w_src is a view of (its packed image is then cached)."""

@@ -97,3 +97,42 @@ def test_batch_norm_matches_torch(lib, R, N, training):
     assert rel_err(mine.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy()) < 1e-5
     assert rel_err(mine.running_var.cpu().numpy(), ref.running_var.cpu().numpy()) < 1e-5
     assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
+def test_packed_weight_cache_follows_the_weights(lib):
+    """The packed GEMM operand of a parameter is cached (ops._PackedWeights): re-used while the weight is unchanged, re-packed when
+    autograd's version counter moves (in-place update, load_state_dict), refreshed by ONE launch by ops.repack_persistent(), and
+    droppable by hand after a write the counter cannot see (param.data...)."""
+    from news_recommendation_model_amd import native, ops
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(24, 10).cuda()
+    x = torch.randn(7, 24, device="cuda")
+
+    def run():
+        native.kernel_events = []
+        with torch.no_grad():
+            y = ops.linear(x, lin.weight, lin.bias)
+        packs = sum(1 for tag, _, _ in native.kernel_events if tag == "nrm_gemm_pack_multi")
+        native.kernel_events = None
+        return y, packs
+    ref = lambda: torch.nn.functional.linear(x, lin.weight, lin.bias)      # noqa: E731
+    ops.invalidate_packed_weights()
+    y, n = run()
+    assert n == 1 and torch.allclose(y, ref(), atol=1e-5)
+    y, n = run()
+    assert n == 0 and torch.allclose(y, ref(), atol=1e-5)                  # cached
+    with torch.no_grad():
+        lin.weight.mul_(2.0)                                               # version counter moves -> lazy re-pack
+    y, n = run()
+    assert n == 1 and torch.allclose(y, ref(), atol=1e-5)
+    lin.weight.data.mul_(0.5)                                              # invisible to the counter ...
+    ops.invalidate_packed_weights()                                        # ... so the caller says so
+    y, n = run()
+    assert n == 1 and torch.allclose(y, ref(), atol=1e-5)
+    lin.weight.data.add_(1.0)
+    assert ops.repack_persistent() >= 1                                    # what FlatAdam.step() does: one launch for all images
+    y, n = run()
+    assert n == 0 and torch.allclose(y, ref(), atol=1e-5)
+    lin.load_state_dict({"weight": torch.ones(10, 24), "bias": torch.zeros(10)})
+    y, n = run()
+    assert n == 1 and torch.allclose(y, ref(), atol=1e-5)
