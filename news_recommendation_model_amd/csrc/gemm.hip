@@ -401,14 +401,15 @@ hipError_t gemm_tn_launch(GemmTnParams p, const GemmTnPlan& pl, hipStream_t st) 
 // ---------------------------------------------------------------------------------------------
 // slab reduction: the partial slabs ws[s][j][i] of gemm_tn / the attention dW_p pass -> the gradient tensor itself
 // (sum over s + transpose + strided placement in ONE launch; was ATen sum(dim=0).t() + cat: 24 reduce launches and a
-// concat per step).  blockDim (32, 8); a block owns a 32(i) x 32(j) tile AND a chunk of the splits (blockIdx.y), so a
+// concat per step).  blockDim (32, 8); a block owns a 128(i) x 32(j) tile AND a chunk of the splits (blockIdx.y), so a
 // 200 MB slab set (324 splits of 400 x 400 at C3) is streamed by thousands of blocks: reads run along i (the slab's fast
 // index), the partial tile is transposed through LDS and ADDED to the output along j with float atomics (the caller
 // zero-initialises `out`; one add per element and split chunk).  blockIdx.y == gridDim.y - 1 sums the bias vectors.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceParams p, int spc) {
-    __shared__ float tile[32][33];
+    // tile = 128 (i, the slab's fast index: one float4 per thread and row) x 32 (j); LDS row stride 129: conflict-free both ways
+    __shared__ float tile[32][129];
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int nbi = (p.ni + 31) / 32;
+    const int nbi = (p.ni + 127) / 128;
     if (blockIdx.y == gridDim.y - 1) {                                 // vector leg (db = sum of per-split column sums)
         if (!p.vec) return;
         const int i = blockIdx.x * 256 + ty * 32 + tx;
@@ -420,27 +421,33 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceParams
         return;
     }
     if ((int)blockIdx.x >= nbi * ((p.nj + 31) / 32)) return;            // grid.x is sized for the longer of the two legs
-    const int i0 = (blockIdx.x % nbi) * 32, j0 = (blockIdx.x / nbi) * 32;
+    const int i0 = (blockIdx.x % nbi) * 128, j0 = (blockIdx.x / nbi) * 32;
     const int s_lo = blockIdx.y * spc, s_hi = min(p.nsplit, s_lo + spc);
     const size_t slab = (size_t)p.nj * p.ldws;
-    float a[4] = {0.f, 0.f, 0.f, 0.f};
-    const int i = i0 + tx;
-    if (i < p.ni) {
+    f32x4 a[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int i = i0 + 4 * tx;
+    if (i < p.ldws) {                                                   // ldws % 4 == 0: the float4 stays inside the padded row
         for (int s = s_lo; s < s_hi; ++s) {
             const float* src = p.ws + s * slab + (size_t)(j0 + ty) * p.ldws + i;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (j0 + ty + 8 * r < p.nj) a[r] += src[(size_t)8 * r * p.ldws];
+                if (j0 + ty + 8 * r < p.nj) a[r] += *reinterpret_cast<const f32x4*>(src + (size_t)8 * r * p.ldws);
         }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) tile[ty + 8 * r][tx] = a[r];           // tile[j][i]
-    __syncthreads();
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int ii = i0 + ty + 8 * r, j = j0 + tx;
-        if (ii < p.ni && j < p.nj) {
-            const float v = tile[tx][ty + 8 * r];
+        for (int e = 0; e < 4; ++e) tile[ty + 8 * r][4 * tx + e] = a[r][e];      // tile[j][i]
+    __syncthreads();
+    const int t = ty * 32 + tx, jj = t & 31;
+    const int j = j0 + jj;
+    if (j < p.nj) {
+        for (int il = t >> 5; il < 128; il += 8) {
+            const int ii = i0 + il;
+            if (ii >= p.ni) break;
+            const float v = tile[jj][il];
             atomicAdd(p.out + ii * p.ors + j * p.ocs, v);
             if (p.out2) atomicAdd(p.out2 + ii * p.ors2 + j * p.ocs2, p.sign2 * v);
         }
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceParams
 
 hipError_t slab_reduce_launch(const SlabReduceParams& p, hipStream_t st) {
     if (p.ni <= 0 || p.nj <= 0) return hipSuccess;
-    const int nbi = (p.ni + 31) / 32, nbj = (p.nj + 31) / 32;
+    const int nbi = (p.ni + 127) / 128, nbj = (p.nj + 31) / 32;
     const int tiles = nbi * nbj;
     int gx = tiles;
     if (p.vec && (p.ni + 255) / 256 > gx) gx = (p.ni + 255) / 256;

@@ -25,8 +25,9 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     trainer.train_step(model, opt, tb)
     torch.cuda.synchronize()
-rows = [e for e in prof.key_averages(group_by_stack_n=6) if e.key.startswith("aten::") and e.device_time_total > 0]
-rows.sort(key=lambda e: -e.count)
-for e in rows[:45]:
-    st = [s for s in e.stack if "news_recommendation_model_amd" in s or "torch/autograd" in s][:2]
-    print(f"{e.count:4d} {e.key:32s} dev_us={e.device_time_total:8.1f}  {' <- '.join(s.split('/')[-1][:70] for s in st)}")
+rows = [e for e in prof.key_averages(group_by_stack_n=12) if e.key.startswith("aten::") and e.device_time_total > 0
+        and e.key in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::add", "aten::fill_", "aten::mul", "aten::sum", "aten::_to_copy")]
+rows.sort(key=lambda e: (e.key, -e.count))
+for e in rows:
+    st = [s for s in e.stack if "news_recommendation_model_amd" in s][:3]
+    print(f"{e.count:4d} {e.key:20s} dev_us={e.device_time_total:7.1f}  {' <- '.join(s.split('news_recommendation_model_amd/')[-1][:60] for s in st) or '(autograd engine)'}")
