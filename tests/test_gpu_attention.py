@@ -213,6 +213,43 @@ def test_full_size_linearity_property(lib):
     assert rel_err(s.detach()[idx].cpu().numpy(), ref.numpy()) < FWD_TOL
 
 
+def test_full_size_c2_bf16x3_properties(lib):
+    """BASELINE config 2 at FULL size (B=512, H=32, T=30, D=256) on the bf16x3 arithmetic: the persistent resident-W forward
+    and the bf16 E-form backward against properties the math offers (too big for the CPU oracle): rows are independent of
+    the rest of the launch (up to the order of the two float atomics per score, which commute exactly), the backward is
+    linear in the upstream gradient, agrees with the fp32-MFMA path of the same kernels' inputs to 1e-4 / 1e-3, and two
+    impressions match the fp32 oracle to the fp32 gate."""
+    from news_recommendation_model_amd import ops
+    torch.manual_seed(1)
+    B, T, H, D = 512, 30, 32, 256
+    k1, k2 = 1 / np.sqrt(4 * D), 1 / np.sqrt(D)
+    w1 = ((torch.rand(D, 4 * D, device="cuda") * 2 - 1) * k1).requires_grad_(True)
+    b1 = (torch.rand(D, device="cuda") * 2 - 1) * k1
+    w2 = (torch.rand(1, D, device="cuda") * 2 - 1) * k2
+    b2 = (torch.rand(1, device="cuda") * 2 - 1) * k2
+    t = torch.randn(B, T, D, device="cuda")
+    h = torch.randn(B, H, D, device="cuda", requires_grad=True)
+    with torch.no_grad():
+        whole = ops.pointwise_attention_scores(t, h, w1, b1, w2, b2, mma="bf16x3")
+        lo = ops.pointwise_attention_scores(t[:200], h[:200], w1, b1, w2, b2, mma="bf16x3")
+        f32 = ops.pointwise_attention_scores(t, h, w1, b1, w2, b2, mma="f32")
+    assert torch.equal(whole[:200], lo)
+    assert rel_err(whole.cpu().numpy(), f32.cpu().numpy()) < 1e-4
+    g = torch.randn_like(whole)
+    s = ops.pointwise_attention_scores(t, h, w1, b1, w2, b2, mma="bf16x3")
+    gh1, gw1 = torch.autograd.grad(s, [h, w1], g)
+    s = ops.pointwise_attention_scores(t, h, w1, b1, w2, b2, mma="bf16x3")
+    gh2, gw2 = torch.autograd.grad(s, [h, w1], 2.0 * g)
+    assert rel_err((gh2 / 2).cpu().numpy(), gh1.cpu().numpy()) < 1e-4 and rel_err((gw2 / 2).cpu().numpy(), gw1.cpu().numpy()) < 1e-4
+    s = ops.pointwise_attention_scores(t, h, w1, b1, w2, b2, mma="f32")
+    gh32, gw32 = torch.autograd.grad(s, [h, w1], g)
+    assert rel_err(gh1.cpu().numpy(), gh32.cpu().numpy()) < 1e-3 and rel_err(gw1.cpu().numpy(), gw32.cpu().numpy()) < 1e-3
+    idx = [5, 400]
+    p = {"a.mlp.fc1.weight": w1.detach().cpu(), "a.mlp.fc1.bias": b1.cpu(), "a.mlp.fc2.weight": w2.cpu(), "a.mlp.fc2.bias": b2.cpu()}
+    ref = orc.pointwise_attention_scores(p, "a", t[idx].cpu(), h[idx].detach().cpu())[..., 0]
+    assert rel_err(whole[idx].cpu().numpy(), ref.numpy()) < FWD_TOL
+
+
 def _fuzz_shapes(n=48, seed=20260101):
     rng = np.random.default_rng(seed)
     shapes = []
@@ -223,6 +260,21 @@ def _fuzz_shapes(n=48, seed=20260101):
         D = int(rng.choice([4, 8, 12, 20, 36, 52, 64, 68, 76, 80, 84, 96, 100, 124, 128, 132, 160, 164, 200, 7, 33, 90]))
         shapes.append((B, T, H, D))
     return shapes
+
+
+@pytest.mark.parametrize("B,T,H,D", _fuzz_shapes(n=16, seed=7))
+def test_random_shapes_match_oracle_bf16x3(lib, B, T, H, D):
+    """The fuzz list on the bf16x3 arithmetic (resident-W forward: slice counts 1..n, ragged last slices, widths that are not
+    multiples of 32; E-form backward with ragged 32-row super-steps), held to the fp32 gates."""
+    rng = np.random.default_rng(B * 100003 + T * 1009 + H * 31 + D)
+    w = _weights(rng, D)
+    tgt = rng.standard_normal((B, T, D)).astype(np.float32)
+    his = rng.standard_normal((B, H, D)).astype(np.float32)
+    gs = rng.standard_normal((B, T, H)).astype(np.float32)
+    s, got, s_ref, ref = _run_both(w, tgt, his, gs, mma="bf16x3")
+    assert rel_err(s, s_ref) < FWD_TOL
+    for k in ref:
+        assert rel_err(got[k], ref[k]) < GRAD_TOL, k
 
 
 @pytest.mark.parametrize("B,T,H,D", _fuzz_shapes())
