@@ -103,7 +103,7 @@ def host_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(dims, wl, seconds, cpu_batch):
+def cpu_baseline(dims, wl, seconds, cpu_batch, mma="f32"):
     """Oracle train step (reference-literal: materialises the [B,T,H,4D] concat) on the host cores."""
     from news_recommendation_model_amd import synth
     from oracle import user_model_oracle as orc
@@ -122,7 +122,7 @@ def cpu_baseline(dims, wl, seconds, cpu_batch):
     check = None
     try:
         from news_recommendation_model_amd import trainer
-        model = trainer.build_model(dims, int(batch["user_num"]), sd, device="cuda").train()
+        model = trainer.build_model(dims, int(batch["user_num"]), sd, device="cuda", attention_mma=mma).train()
         gb = trainer.batch_to_device(batch, "cuda")
         out = model(gb["x_history"], gb["x_target"], gb["x_global"])
         gl = model.loss(gb["user_id"], out, gb["label"])
@@ -151,22 +151,23 @@ def cpu_baseline(dims, wl, seconds, cpu_batch):
             "hip_vs_oracle_first_step": check}
 
 
-def fwd_auc_parity(dev):
-    """The 'fwd AUC parity' half of the headline metric: forward of the C3-shaped golden case (B=2, H=50, T=30,
-    D=400; outputs of the REFERENCE model, tests/golden/c3_large.npz) through the HIP path; max relative error of
-    the logits and max |AUC difference| per impression against the fixture."""
+def fwd_auc_parity(dev, mma="f32", case_name="c3_large"):
+    """The 'fwd AUC parity' half of the headline metric: forward of a golden case at the benchmarked shape's dimensions
+    (c3_large: B=2, H=50, T=30, D=400; c2_small: B=2, H=32, T=30, D=256; outputs of the REFERENCE model,
+    tests/golden/*.npz) through the HIP path IN THE ARITHMETIC BEING BENCHMARKED; max relative error of the logits and max
+    |AUC difference| per impression against the fixture."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     try:
         from golden_util import load_case
         from news_recommendation_model_amd import evaluation, trainer
-        case, dims, batch, sd, fx = load_case("c3_large")
-        model = trainer.build_model(dims, int(batch["user_num"]), sd, device=dev).train()
+        case, dims, batch, sd, fx = load_case(case_name)
+        model = trainer.build_model(dims, int(batch["user_num"]), sd, device=dev, attention_mma=mma).train()
         tb = trainer.batch_to_device(batch, dev)
         with torch.no_grad():
             out = model(tb["x_history"], tb["x_target"], tb["x_global"])
         auc, _ = evaluation.row_auc_top1(out, tb["label"])
         r = out.cpu().numpy()
-        return {"case": "c3_large (reference fixture)", "logit_max_rel_err": float(np.abs(r - fx["r"]).max() / np.abs(fx["r"]).max()),
+        return {"case": f"{case_name} (reference fixture), attention arithmetic {mma}", "logit_max_rel_err": float(np.abs(r - fx["r"]).max() / np.abs(fx["r"]).max()),
                 "auc_max_abs_diff": float(np.abs(auc.cpu().numpy() - fx["auc"]).max())}
     except Exception as e:                      # never let the parity probe break the throughput line
         return {"error": repr(e)}
@@ -430,9 +431,10 @@ def main():
         }
         if pcie is not None:
             line["pcie_inclusive"] = pcie
-        line["fwd_auc_parity"] = fwd_auc_parity(dev)
+        line["fwd_auc_parity"] = fwd_auc_parity(dev, args.dtype, {"C2-small": "c2_small", "C1-demo": "c1_demo", "C5-long": "c5_long",
+                                                                  "ref-default": "refdefault"}.get(args.workload, "c3_large"))
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(dims, wl, args.cpu_seconds, args.cpu_batch)
+            line["cpu_baseline"] = cpu_baseline(dims, wl, args.cpu_seconds, args.cpu_batch, args.dtype)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()                 # rank 0 is still printing / probing parity: leave together
