@@ -59,8 +59,8 @@ int nrm_pwattn_fwd(const float* t, const float* h, const float* u, const float* 
  * ds [B,T,H]; du [B,H,D] and dv [B,T,D] are overwritten (histories longer than 256 rows are processed in chunks). */
 int nrm_pwattn_bwd_dz(float* z_inout, const float* ds, const float* w2, float* dw2, float* du, float* dv,
                       int B, int T, int H, int D, nrm_stream_t stream);
-/* number of [D,D] partial slabs nrm_pwattn_bwd_contract writes into `ws` */
-int nrm_pwattn_bwd_nsplit(int B, int T, int H, int D);
+/* number of [D,D] partial slabs nrm_pwattn_bwd_contract writes into `ws` (depends on the arithmetic: tile shapes differ) */
+int nrm_pwattn_bwd_nsplit(int B, int T, int H, int D, int mma);
 /* backward, step 2 (the bilinear term): given dz [B,T,H,D], t, h and W_p (row stride ldwp)
  *   dt[b,t,d] += sum_{h,k} dz W_p[k,d] h[b,h,d]      dh[b,h,d] += sum_{t,k} dz W_p[k,d] t[b,t,d]
  *   ws[i][d][k] (i < nsplit) = partial of dW_p[k,d] = sum_{b,t,h} dz[b,t,h,k] t[b,t,d] h[b,h,d]

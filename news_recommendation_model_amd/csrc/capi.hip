@@ -108,11 +108,11 @@ int nrm_pwattn_bwd_dz(float* z_inout, const float* ds, const float* w2, float* d
     return check_hip(nrm::bwd_dz_launch(z_inout, ds, w2, dw2, du, dv, B, T, H, D, (hipStream_t)stream), "bwd_dz");
 }
 
-int nrm_pwattn_bwd_nsplit(int B, int T, int H, int D) {
+int nrm_pwattn_bwd_nsplit(int B, int T, int H, int D, int mma) {
     if (B <= 0 || T <= 0 || H <= 0 || D <= 0) return 0;
     int tw1 = kBtWaves;
     if (const char* e = getenv("NRM_BT_WAVES")) tw1 = atoi(e);
-    return nrm::bwd_e_plan(D, B * T, tw1, kBtMinGroups).nsplit;
+    return nrm::bwd_e_plan(D, B * T, tw1, kBtMinGroups, mma).nsplit;
 }
 
 int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, const float* wp, int ldwp,
@@ -136,7 +136,7 @@ int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, con
         p.G = B * T; p.G2 = T; p.R = H; p.D = D;
         int tw1 = kBtWaves;
         if (const char* e = getenv("NRM_BT_WAVES")) tw1 = atoi(e);
-        const nrm::BwdEPlan pl = nrm::bwd_e_plan(D, p.G, tw1, kBtMinGroups);
+        const nrm::BwdEPlan pl = nrm::bwd_e_plan(D, p.G, tw1, kBtMinGroups, mma);
         if (int rc = check_hip(nrm::bwd_e_launch(p, pl, true, mma, (hipStream_t)stream), "bwd_e pass 1")) return rc;
     }
     // pass 2: groups (b,h); rows r = t.  X_g = dz[b,:,h,:], Y_g = t[b];  out = dh
@@ -149,7 +149,7 @@ int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, con
         // this variant keeps no dW_p accumulators (<= 168 VGPRs): three waves per SIMD
         int tw = kBhWaves;
         if (const char* e = getenv("NRM_BH_WAVES")) tw = atoi(e);
-        const nrm::BwdEPlan pl = nrm::bwd_e_plan(D, p.G, tw);
+        const nrm::BwdEPlan pl = nrm::bwd_e_plan(D, p.G, tw, 1, mma);
         if (int rc = check_hip(nrm::bwd_e_launch(p, pl, false, mma, (hipStream_t)stream), "bwd_e pass 2")) return rc;
     }
     return NRM_OK;

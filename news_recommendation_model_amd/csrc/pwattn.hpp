@@ -49,7 +49,7 @@ struct BwdEParams {
     int nsplit;
 };
 struct BwdEPlan { int DT, KT, ndcol, nkw, nsplit, gps; };
-BwdEPlan bwd_e_plan(int D, int G, int target_waves, int min_gps = 1);
+BwdEPlan bwd_e_plan(int D, int G, int target_waves, int min_gps = 1, int mma = 0);
 hipError_t bwd_e_launch(const BwdEParams& p, const BwdEPlan& pl, bool with_dw, int mma, hipStream_t st);
 hipError_t bwd_dz_launch(float* z, const float* ds, const float* w2, float* dw2, float* du, float* dv,
                          int B, int T, int H, int D, hipStream_t st);

@@ -707,11 +707,14 @@ __global__ __launch_bounds__(256, 2) void bwd_e_pipe_kernel(const BwdEParams p) 
 // min_gps: lower bound on the groups a split walks.  The dt/dW pass passes 96: every split of it writes a [D, D] partial
 // slab of dW_p (C2-small at the old 40 groups per split: 384 slabs = 100 MB for a 256 KB gradient; 5.73 -> 5.68 ms per step
 // with 120); C3's 126 groups per split are unaffected.
-BwdEPlan bwd_e_plan(int D, int G, int target_waves, int min_gps) {
+BwdEPlan bwd_e_plan(int D, int G, int target_waves, int min_gps, int mma) {
     const int n16 = (D + 15) / 16;
     const int c5 = (n16 + 4) / 5 * 5, c4 = (n16 + 3) / 4 * 4;
     BwdEPlan pl;
     if (c5 < c4) { pl.DT = 5; pl.KT = 5; } else { pl.DT = 4; pl.KT = 4; }   // the shape that pads less
+    // bf16 forms: always 4x4 -- their operand fragments (and the hi/lo split) do not fit beside 5x5 accumulators at two
+    // waves per SIMD, and padded MFMAs are cheap there (C3, bf16x3, dt+dW pass: 4.49 ms on 5x5 tiles at one wave per SIMD)
+    if (mma != 0) { pl.DT = 4; pl.KT = 4; }
     pl.ndcol = (n16 + pl.DT - 1) / pl.DT;
     pl.nkw = (n16 + pl.KT - 1) / pl.KT;
     const int tiles = pl.ndcol * pl.nkw;

@@ -24,7 +24,7 @@ SIGNATURES = {
     "nrm_pwattn_pack_wp": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp]),
     "nrm_pwattn_fwd": (_c_i, [_c_fp] * 9 + [_c_i] * 5 + [_c_fp]),
     "nrm_pwattn_bwd_dz": (_c_i, [_c_fp] * 6 + [_c_i] * 4 + [_c_fp]),
-    "nrm_pwattn_bwd_nsplit": (_c_i, [_c_i] * 4),
+    "nrm_pwattn_bwd_nsplit": (_c_i, [_c_i] * 5),
     "nrm_pwattn_bwd_contract": (_c_i, [_c_fp] * 4 + [_c_i] + [_c_fp] * 3 + [_c_i] * 6 + [_c_fp]),
     "nrm_gemm_packed_floats": (_c_l, [_c_i, _c_i]),
     "nrm_gemm_pack": (_c_i, [_c_fp, _c_l, _c_l, _c_i, _c_i, _c_fp, _c_fp]),

@@ -317,7 +317,7 @@ def _pwattn_bwd_impl(ds, t, h, w1, w2, z, mma):
     # du (W_h - W_d), dv (W_t + W_d): the transposed orientation of the same two combinations   (D % 4 == 0: contiguous results)
     dh = _gemm_nt(du2, w_h, 1, 4 * D, D, D, None, EPI_BIAS, src2=w_d, sign2=-1.0, owner=own)[0].reshape(B, H, D)
     dt = _gemm_nt(dv2, w_t, 1, 4 * D, D, D, None, EPI_BIAS, src2=w_d, sign2=1.0, owner=own)[0].reshape(B, T, D)
-    nsplit = native.load().nrm_pwattn_bwd_nsplit(B, T, H, D)
+    nsplit = native.load().nrm_pwattn_bwd_nsplit(B, T, H, D, mma)
     wsp = torch.empty(nsplit, D, D, dtype=torch.float32, device=dev)
     wp = w1[:, 3 * D:]                                   # view, row stride 4D
     # two launches: (b,t)-grouped -> dt + dW_p slabs, (b,h)-grouped -> dh (issued separately so that

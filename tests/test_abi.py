@@ -27,8 +27,8 @@ def test_abi_version_and_sizes(lib):
     for D in (64, 72, 256, 400, 768):
         n16 = (D + 15) // 16
         assert lib.nrm_pwattn_packed_floats(D) >= n16 * 16 * n16 * 16
-    assert lib.nrm_pwattn_bwd_nsplit(1024, 30, 50, 400) >= 1
-    assert lib.nrm_pwattn_bwd_nsplit(1, 1, 1, 64) == 1
+    assert lib.nrm_pwattn_bwd_nsplit(1024, 30, 50, 400, 0) >= 1
+    assert lib.nrm_pwattn_bwd_nsplit(1, 1, 1, 64, 0) == 1
 
 
 def test_host_validation_rejects_bad_shapes(lib):
