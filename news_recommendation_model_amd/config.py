@@ -8,8 +8,7 @@ re-dimension the model by editing ``model_config`` (or by passing an explicit
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
-from typing import List
+from dataclasses import dataclass
 
 model_config = {
     # reference configs/model_config.py:4  (ids 0..2999, 0 = padding)

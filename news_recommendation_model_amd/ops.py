@@ -125,7 +125,7 @@ def _pack(src, rs, cs, nrows, ncols, src2=None, sign2=0.0, owner=None):
     if owner is None:
         buf = torch.empty(lib.nrm_gemm_packed_floats(nrows, ncols), dtype=torch.float32, device=src.device)
         d = _pack_desc(src, rs, cs, nrows, ncols, src2, sign2, buf)
-        native.call("nrm_gemm_pack_multi", ctypes_ref(d), 1, native.stream_ptr())
+        native.call("nrm_gemm_pack_multi", _ctypes_ref(d), 1, native.stream_ptr())
         return buf
     key = (src.data_ptr(), int(rs), int(cs), int(nrows), int(ncols), src2.data_ptr() if src2 is not None else 0, float(sign2))
     ent = _packs.entries.get(key)
@@ -140,12 +140,12 @@ def _pack(src, rs, cs, nrows, ncols, src2=None, sign2=0.0, owner=None):
         ent.spec = (src, rs, cs, nrows, ncols, src2, sign2)          # views keep the parameter's storage alive
         _packs.entries[key] = ent
     d = _pack_desc(src, rs, cs, nrows, ncols, src2, sign2, ent.buf)
-    native.call("nrm_gemm_pack_multi", ctypes_ref(d), 1, native.stream_ptr())
+    native.call("nrm_gemm_pack_multi", _ctypes_ref(d), 1, native.stream_ptr())
     ent.version, ent.epoch = owner._version, _packs.epoch
     return ent.buf
 
 
-def ctypes_ref(desc_or_array):
+def _ctypes_ref(desc_or_array):
     import ctypes
     return ctypes.cast(ctypes.pointer(desc_or_array), ctypes.c_void_p)
 
@@ -165,7 +165,7 @@ def repack_persistent(device=None):
     if not live:
         return 0
     arr = (native.PackDesc * len(live))(*[_pack_desc(*ent.spec, ent.buf) for ent, _ in live])
-    native.call("nrm_gemm_pack_multi", ctypes_ref(arr), len(live), native.stream_ptr())
+    native.call("nrm_gemm_pack_multi", _ctypes_ref(arr), len(live), native.stream_ptr())
     for ent, owner in live:
         ent.version, ent.epoch = owner._version, _packs.epoch
     return len(live)

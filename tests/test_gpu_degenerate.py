@@ -5,7 +5,6 @@ user_model.py:31-43)."""
 import json
 import os
 
-import numpy as np
 import pytest
 import torch
 
