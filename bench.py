@@ -236,7 +236,12 @@ def main():
     backend = os.environ.get("NRM_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # NRM_DIST_WORLD1=1: bring the process group up even for one rank, so that a one-GPU box exercises RCCL itself
+    # (library load, communicator, the in-stream all-reduce of the flat gradient, barrier) on the code path of N > 1
+    use_dist = world > 1 or os.environ.get("NRM_DIST_WORLD1") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -263,11 +268,11 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if not args.graph and not args.eager and world == 1:
+    if not args.graph and not args.eager and world == 1 and not use_dist:
         # launch mode by measurement: two eager steps (after two warm-up steps), mean wall time per step
         for _ in range(2):
             trainer.train_step(model, opt, tb, reducer)
@@ -323,7 +328,7 @@ def main():
         events, native.kernel_events, native.kernel_event_tags = native.kernel_events, None, None
         # heavy kernels: timed region; everything else: the 3 bracketed warm-up steps
         events = events + [e for e in table_events if e[0] not in HEAVY]
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -420,14 +425,14 @@ def main():
             "config": {"workload": f"{args.workload}: EBNeRD-large-shape synthetic" if args.workload == "C3-large" else args.workload,
                        "per_gpu_batch": B, "global_batch": world * B, "hist": H, "candidates": T, "emb": D,
                        "user_num": user_num, "parallelism": f"dp{world}", "launch": "hipGraph replay" if args.graph else "eager, untimed kernels" if args.no_kernel_timing else "eager",
-                       "step": "fwd+loss+bwd+allreduce+Adam(wd=1e-5)" if world > 1 else "fwd+loss+bwd+Adam(wd=1e-5)"},
+                       "step": "fwd+loss+bwd+allreduce+Adam(wd=1e-5)" if use_dist else "fwd+loss+bwd+Adam(wd=1e-5)"},
             "loss": round(float(loss), 6),
             "roofline": dict(roof, traffic=traffic, traffic_source=traffic_note),
             "kernels": {k: {"launches": v["launches"], "mean_ms": round(v["mean_ms"], 4)} for k, v in kern.items()},
-            "grad_allreduce_bytes": opt.nbytes if world > 1 else 0, "replicas_in_sync": replicas_in_sync,
+            "grad_allreduce_bytes": opt.nbytes if use_dist else 0, "replicas_in_sync": replicas_in_sync,
             "collective": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                             "all_reduce_per_step": 1, "launcher": "self (child processes)" if os.environ.get("NRM_BENCH_CHILD") else "external"}
-                           if world > 1 else None),
+                           if use_dist else None),
         }
         if pcie is not None:
             line["pcie_inclusive"] = pcie
@@ -436,7 +441,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(dims, wl, args.cpu_seconds, args.cpu_batch, args.dtype)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()                 # rank 0 is still printing / probing parity: leave together
         dist.destroy_process_group()
 

@@ -143,10 +143,16 @@ class FlatAdam:
     def all_reduce_grads(self, group=None):
         """The ONE collective of a data-parallel step: sum the flat gradient over ranks, then average."""
         self.collect_grads()
-        world = dist.get_world_size(group) if dist.is_initialized() else 1
-        if world > 1:
+        if not dist.is_initialized():
+            return
+        # issued whenever a process group exists, also for a group of one (bench.py's NRM_DIST_WORLD1 rehearsal of RCCL)
+        world = dist.get_world_size(group)
+        if dist.get_backend(group) == "nccl":
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.AVG, group=group)      # RCCL averages in the collective
+        else:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)
-            self.flat_grad.mul_(1.0 / world)
+            if world > 1:
+                self.flat_grad.mul_(1.0 / world)
 
 
 class FlatGradReducer:

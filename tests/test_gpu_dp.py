@@ -75,3 +75,31 @@ def test_bench_self_launches_two_ranks(lib, tmp_path):
     assert line["replicas_in_sync"] is True
     assert line["grad_allreduce_bytes"] > 0
     assert line["collective"]["world_size"] == 2 and line["collective"]["all_reduce_per_step"] == 1
+
+
+def test_bench_one_rank_through_rccl(lib, tmp_path):
+    """RCCL itself under the data-parallel step, as far as a one-GPU box can take it: a process group of ONE rank with
+    backend nccl (NRM_DIST_WORLD1=1), so the communicator, the in-stream all-reduce of the flat gradient (ReduceOp.AVG),
+    the barrier-bracketed timing and the replica check of bench.py all run through librccl on the code path of N > 1."""
+    env = dict(os.environ, NRM_DIST_WORLD1="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "NRM_DIST_BACKEND", "NRM_SINGLE_DEVICE"):
+        env.pop(k, None)
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                         "--workload", "ref-default", "--batch", "16", "--no-cpu-baseline"],
+                        env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+    assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in pr.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, pr.stdout.decode()[-2000:]
+    line = json.loads(lines[0])
+    assert line["collective"]["backend"] == "nccl" and line["collective"]["world_size"] == 1
+    assert line["grad_allreduce_bytes"] > 0 and line["replicas_in_sync"] is True
+    assert line["config"]["launch"] == "eager"
+    # the one-rank average must leave the step itself unchanged: same loss as the run without a process group
+    env.pop("NRM_DIST_WORLD1")
+    pr2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                          "--workload", "ref-default", "--batch", "16", "--no-cpu-baseline", "--eager"],
+                         env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+    assert pr2.returncode == 0, pr2.stderr.decode(errors="replace")[-3000:]
+    line2 = json.loads([ln for ln in pr2.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert abs(line["loss"] - line2["loss"]) <= 1e-5 * max(1.0, abs(line2["loss"]))
