@@ -213,6 +213,9 @@ __global__ __launch_bounds__(256, (MMA && KT > 4) || (MMA == 2 && WITH_DW) ? 1 :
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-descriptor builtins: device pass only (keeps the host stub)
     static_assert(KS == DT, "one pass over the whole d range per group (the 3+2 sub-pass split is gone)");
     constexpr bool BF16 = MMA != 0;
+    // epilogue with the W_p^T reads two tiles ahead (and step 1 of the next group requested after it): pays on 5x5 tiles
+    // (C3: 4.57 -> 4.48 ms); on 4x4 tiles the serial one-read-one-FMA form is faster (C5, D = 768: 20.6 vs 23.2 ms)
+    constexpr bool AHEAD = WITH_DW && NRM_EPI_AHEAD && !BF16 && KT == 5;
     constexpr int LDK = KT * 16 + 8;      // padded row of the W_p^T tile: +8 is conflict-free under gfx950 b128 lane groups (+4 is 2-way)
     __shared__ __attribute__((aligned(16))) float smem[DT * 16 * LDK + 4 * DT * 16];
     float* wpt = smem;                                                  // [DT*16 d][LDK]  = W_p[k0+k][d0+d]
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(256, (MMA && KT > 4) || (MMA == 2 && WITH_DW) ? 1 :
             // WITH_DW: step 1 of the next group is requested AFTER the epilogue arithmetic (still before this group's float
             // atomics, which vmcnt would otherwise put in front of it): operand set 1 is dead during the epilogue, and
             // those registers let the W_p^T reads run two tiles ahead of their FMAs instead of being waited one by one
-            if (!(WITH_DW && NRM_EPI_AHEAD) && nsteps > 1) load_step(a1, b1, 1);
+            if (!AHEAD && nsteps > 1) load_step(a1, b1, 1);
         }
         }
 
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(256, (MMA && KT > 4) || (MMA == 2 && WITH_DW) ? 1 :
             if (keep == 123.456f) bounce[r16] = keep;
             return;
         }
-        if (WITH_DW && NRM_EPI_AHEAD && !BF16) {
+        if (AHEAD) {
             // flattened (jt, it) order, LDS reads two tiles ahead of their FMAs
             constexpr int NTILE = KT * DT;
             auto rd = [&](int n) { return *reinterpret_cast<const f32x4*>(&wpt[(16 * (n / KT) + r16) * LDK + 16 * (n % KT) + 4 * q]); };
@@ -746,7 +749,9 @@ static hipError_t launch_e_t(BwdEParams p, const BwdEPlan& pl, bool with_dw, int
     const dim3 grid(pl.nkw * pl.ndcol, (pl.nsplit + 3) / 4), block(256);
     const bool exact = p.D % (16 * KT) == 0 && p.D % (16 * DT) == 0;
     constexpr int KS_DW = DT;     // single pass (40 B of scratch at 5x5); the 3+2 sub-pass split is KS_DW = (DT + 1) / 2
-    if (mma == 1 || mma == 2) {
+    if constexpr (KT != 4) {
+        if (mma != 0) return hipErrorInvalidValue;      // bwd_e_plan gives the bf16 forms 4x4 tiles only
+    } else if (mma == 1 || mma == 2) {
 #define NRM_LAUNCH_E(M)                                                                                              \
         if (with_dw) {                                                                                               \
             if (exact) hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, true, M>), grid, block, 0, st, p);       \
