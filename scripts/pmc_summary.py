@@ -28,8 +28,9 @@ dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "news_recomme
                             capture_output=True, text=True).stdout.strip())
 stamp = {"kernel_sources_sha256": build.sources_digest(), "git_head": head + ("+uncommitted kernel edits" if dirty else "")}
 
-stats = glob.glob(f"{src}/stats/*/*_kernel_stats.csv")[0]
-trace = glob.glob(f"{src}/stats/*/*_kernel_trace.csv")[0]
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)      # gpurun merges every run into the same directory
+stats = newest(f"{src}/stats/*/*_kernel_stats.csv")
+trace = newest(f"{src}/stats/*/*_kernel_trace.csv")
 shutil.copy(stats, f"{pre}_bench_kernel_stats.csv")
 # steps in the profiled run = launches of the once-per-step Adam kernel
 steps = sum(1 for r in csv.DictReader(open(trace)) if "adam_dev_kernel" in r["Kernel_Name"])
@@ -41,7 +42,7 @@ print(summary)
 
 out = {}
 for leg in ("sq", "fetch", "write"):
-    path = glob.glob(f"{src}/{leg}/*/*_counter_collection.csv")[0]
+    path = newest(f"{src}/{leg}/*/*_counter_collection.csv")
     rows = [r for r in csv.DictReader(open(path)) if "nrm::" in r["Kernel_Name"]]
     name = lambda r: r["Kernel_Name"].split("(")[0].replace("void nrm::", "").replace("nrm::", "")   # noqa: E731
     # the same instantiation is also launched on small shapes (parity probe, side GEMMs): keep the largest grid only
