@@ -137,6 +137,11 @@ int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, con
         int tw1 = kBtWaves;
         if (const char* e = getenv("NRM_BT_WAVES")) tw1 = atoi(e);
         const nrm::BwdEPlan pl = nrm::bwd_e_plan(D, p.G, tw1, kBtMinGroups, mma);
+        // big groups (C5: 128 rows x 768 columns = 393 KB of dz each): the waves of a workgroup walk neighbouring groups, which
+        // cuts what an XCD's L2 must hold -- FETCH_SIZE of this pass at C5 26.3 -> 8.0 GB, same duration (the MALL had been
+        // absorbing the re-reads); small groups keep the blocked walk.  NRM_BT_INTERLEAVE=0|1 forces either (tests).
+        p.interleave = (long)p.R * D * (long)sizeof(float) > (256L << 10);
+        if (const char* e = getenv("NRM_BT_INTERLEAVE")) p.interleave = atoi(e);
         if (int rc = check_hip(nrm::bwd_e_launch(p, pl, true, mma, (hipStream_t)stream), "bwd_e pass 1")) return rc;
     }
     // pass 2: groups (b,h); rows r = t.  X_g = dz[b,:,h,:], Y_g = t[b];  out = dh
@@ -150,6 +155,8 @@ int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, con
         int tw = kBhWaves;
         if (const char* e = getenv("NRM_BH_WAVES")) tw = atoi(e);
         const nrm::BwdEPlan pl = nrm::bwd_e_plan(D, p.G, tw, 1, mma);
+        p.interleave = (long)p.R * D * (long)sizeof(float) > (256L << 10);       // read by the serial kernel only (bf16 forms, short T)
+        if (const char* e = getenv("NRM_BT_INTERLEAVE")) p.interleave = atoi(e);
         if (int rc = check_hip(nrm::bwd_e_launch(p, pl, false, mma, (hipStream_t)stream), "bwd_e pass 2")) return rc;
     }
     return NRM_OK;

@@ -47,6 +47,7 @@ struct BwdEParams {
     int gps;                              // groups per split
     int nkw, ndcol;                       // k-ranges and d-columns of the wave-tile grid
     int nsplit;
+    int interleave;                       // serial kernel: the 4 waves of a workgroup walk one group range round-robin
 };
 struct BwdEPlan { int DT, KT, ndcol, nkw, nsplit, gps; };
 BwdEPlan bwd_e_plan(int D, int G, int target_waves, int min_gps = 1, int mma = 0);

@@ -253,8 +253,16 @@ __global__ __launch_bounds__(256, (MMA && KT > 4) || (MMA == 2 && WITH_DW) ? 1 :
 
     const int split = sgrp * 4 + wave;
     if (split >= p.nsplit) return;
-    const int g_lo = split * p.gps;
-    const int g_hi = min(p.G, g_lo + p.gps);
+    // Group walk of a wave.  Blocked: the gps consecutive groups of its split.  Interleaved (p.interleave): the 4 waves of the
+    // workgroup walk ONE range of 4*gps groups round-robin, so at any time they sit on neighbouring groups -- mostly the
+    // same g1, i.e. the same Y rows, and a quarter of the distinct rows in flight per XCD (what the L2 has to hold).
+    int g_lo = split * p.gps, g_step = 1;
+    int g_hi = min(p.G, g_lo + p.gps);
+    if (p.interleave) {
+        const int nact = min(4, p.nsplit - sgrp * 4);
+        g_lo = sgrp * 4 * p.gps + wave; g_step = nact;
+        g_hi = min(p.G, (sgrp * 4 + nact) * p.gps);
+    }
     const int nsteps = (R + 3) >> 2;
 
     // Operands stream from global memory straight into MFMA operand registers through buffer descriptors
@@ -407,7 +415,7 @@ __global__ __launch_bounds__(256, (MMA && KT > 4) || (MMA == 2 && WITH_DW) ? 1 :
 
         // epilogue: lane holds E[k = k0 + tile_col(it, 4q+e)][d = d0 + tile_col(jt, r16)]; the LDS image of W_p^T is
         // in tile-major order (tile_pos), so its rows/columns are addressed by 16*tile + lane-row as the accumulators are
-        if (NRM_DIAG_NOEPI && g + 1 < g_hi) {                        // timing diagnostic: one cheap use keeps E alive
+        if (NRM_DIAG_NOEPI && gn < g_hi) {                           // timing diagnostic: one cheap use keeps E alive
             float keep = 0.f;
 #pragma unroll
             for (int it = 0; it < KT; ++it)
@@ -474,11 +482,11 @@ __global__ __launch_bounds__(256, (MMA && KT > 4) || (MMA == 2 && WITH_DW) ? 1 :
         }
     }
     diag_first = false;
-    for (int g = g_lo; g < g_hi; ++g) {
-        group_pass(g, g + 1);
+    for (int g = g_lo; g < g_hi; g += g_step) {
+        group_pass(g, g + g_step);
         // k-partial of out[g, d0 .. d0+DT*16): one dword per lane, contiguous segments.
         // bounce[] is wave-private: LDS ops of one wave complete in order, the fences only pin hipcc.
-        if (NRM_DIAG_NOEPI && g + 1 < g_hi) continue;
+        if (NRM_DIAG_NOEPI && g + g_step < g_hi) continue;
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         __builtin_amdgcn_wave_barrier();
         float* orow = p.out + (long)g * p.ldo + d0;

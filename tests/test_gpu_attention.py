@@ -291,3 +291,28 @@ def test_random_shapes_match_oracle(lib, B, T, H, D):
     assert rel_err(s, s_ref) < FWD_TOL
     for k in ref:
         assert rel_err(got[k], ref[k]) < GRAD_TOL, k
+
+
+# The dt/dW pass has two group walks (csrc/capi.hip): blocked (every wave its own run of groups) and interleaved (the four
+# waves of a workgroup share one run round-robin; default for groups above 256 KB, i.e. C5).  Both must give the same
+# gradients for any number of groups / splits, including a last workgroup with fewer than four active waves.
+@pytest.mark.parametrize("mma", ["f32", "bf16x3"])
+@pytest.mark.parametrize("B,T,H,D", [(2, 30, 50, 400), (3, 7, 19, 72), (5, 1, 3, 64), (1, 4, 9, 420), (7, 5, 37, 100),
+                                     (1, 1, 1, 64), (2, 3, 130, 768)])
+def test_interleaved_group_walk_matches_oracle(lib, monkeypatch, mma, B, T, H, D):
+    rng = np.random.default_rng(B * 1000 + T * 100 + H * 10 + D + 1)
+    w = _weights(rng, D)
+    tgt = rng.standard_normal((B, T, D)).astype(np.float32)
+    his = rng.standard_normal((B, H, D)).astype(np.float32)
+    gs = rng.standard_normal((B, T, H)).astype(np.float32)
+    out = {}
+    for walk in ("0", "1"):
+        monkeypatch.setenv("NRM_BT_INTERLEAVE", walk)
+        s, got, s_ref, ref = _run_both(w, tgt, his, gs, mma=mma)
+        assert rel_err(s, s_ref) < FWD_TOL
+        for k in ref:
+            assert rel_err(got[k], ref[k]) < GRAD_TOL, (walk, k, rel_err(got[k], ref[k]))
+        out[walk] = got
+    # the two walks differ only in the order in which float atomics and slab sums meet
+    for k in out["0"]:
+        assert rel_err(out["1"][k], out["0"][k]) < 1e-4, k
