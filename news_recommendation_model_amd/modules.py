@@ -17,6 +17,8 @@ ops go through the C-ABI HIP kernels (ops.py) and raise on CPU tensors.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -151,12 +153,46 @@ class UserInvariantInterestModel(nn.Module):
         lab_h = ops.linear(lab_h, self.w1.weight, self.w1.bias)
         ec = ops.concat_last((lab_t, ti_t))
 
-        s_lab = self.label_attention(lab_t, lab_h)                     # [B,T,H,1]
-        s_ti = self.text_img_attention(ti_t, ti_h)
-        # un-normalised weighted pool: sum_h score * history  (no softmax, padding not masked)
-        pooled_lab = ops.weighted_pool(s_lab.squeeze(-1), lab_h)
-        pooled_ti = ops.weighted_pool(s_ti.squeeze(-1), ti_h)
+        # The two attentions (label features / text+image vector) share no data until the concat.  When their kernels do not
+        # fill the chip (small B*T*H: C1, C2, the reference's default sizes) the second one is issued on a side stream, so it
+        # overlaps the first -- in eager mode and as two parallel branches of the captured HIP graph; autograd runs every
+        # backward node on the stream of its forward and joins the streams at the end of backward().  Full-size batches (C3,
+        # C5: every launch is several waves of workgroups deep) keep one stream.
+        side = ops.branch_stream(lab_t) if self._two_streams(lab_t, lab_h) else None
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            ti_t.record_stream(side)            # allocated on the main stream, read by side-stream kernels (forward and backward)
+            ti_h.record_stream(side)
+            with torch.cuda.stream(side):
+                pooled_ti = self._attend_and_pool(self.text_img_attention, ti_t, ti_h)
+            pooled_lab = self._attend_and_pool(self.label_attention, lab_t, lab_h)
+            main.wait_stream(side)
+            pooled_ti.record_stream(main)
+        else:
+            pooled_lab = self._attend_and_pool(self.label_attention, lab_t, lab_h)
+            pooled_ti = self._attend_and_pool(self.text_img_attention, ti_t, ti_h)
         return ops.concat_last((pooled_lab, pooled_ti)), ec
+
+    @staticmethod
+    def _attend_and_pool(attention, t, h):
+        s = attention(t, h)                                            # [B,T,H,1]
+        # un-normalised weighted pool: sum_h score * history  (no softmax, padding not masked)
+        return ops.weighted_pool(s.squeeze(-1), h)
+
+    two_streams = None          # None: by size; True / False force it (env NRM_BRANCH_STREAMS=0|1 overrides both)
+
+    def _two_streams(self, t, h):
+        return self.uses_two_streams(t.shape[0] * t.shape[1] * h.shape[1] * h.shape[2])
+
+    def uses_two_streams(self, z_elems):
+        """Whether forward() issues its second attention on the side stream for attentions of ``z_elems`` = B*T*H*D."""
+        forced = os.environ.get("NRM_BRANCH_STREAMS")
+        if forced is not None:
+            return forced == "1"
+        if self.two_streams is not None:
+            return bool(self.two_streams)
+        return z_elems <= ops.BRANCH_STREAMS_MAX_ELEMS
 
 
 class UserInstantInterestModel(nn.Module):

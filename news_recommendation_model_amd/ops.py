@@ -896,6 +896,21 @@ def weighted_pool(scores, history):
 _index_error_flag = {}
 
 
+# z elements (B*T*H*D) of one attention up to which UserInvariantInterestModel runs its two attentions on two streams:
+# C2-small (126 M) and smaller overlap, C3 (614 M) and C5 do not
+BRANCH_STREAMS_MAX_ELEMS = 200_000_000
+_branch_streams = {}
+
+
+def branch_stream(like):
+    """The side stream of ``like``'s device (one per device and process, created on first use)."""
+    key = like.device.index if like.device.index is not None else torch.cuda.current_device()
+    st = _branch_streams.get(key)
+    if st is None:
+        st = _branch_streams[key] = torch.cuda.Stream(device=like.device)
+    return st
+
+
 def index_error_flag(device):
     """Device int32 set to 1 by the front-end / loss kernels when a packed row holds an out-of-range table index or a
     user id outside delta (the reference raises IndexError there; the kernels clamp, flag and go on).  Reading it

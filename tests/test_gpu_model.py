@@ -426,3 +426,51 @@ def test_flat_adam_collects_every_gradient_with_one_launch(lib):
     assert all(p.grad is None for p in opt.params)
     opt.collect_grads()                                       # idempotent until the next step
     assert torch.equal(opt.grad_view(0), grads[0])
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_two_stream_attention_branches_match_one_stream(lib, monkeypatch, graphed):
+    """modules.UserInvariantInterestModel.forward issues its second attention (and pool) on a side stream for small
+    shapes: eager and captured into a HIP graph, forward, every gradient and three optimizer steps must land where the
+    one-stream step lands (same kernels; only the order of float atomics can differ)."""
+    from news_recommendation_model_amd import trainer
+    monkeypatch.delenv("NRM_BRANCH_STREAMS", raising=False)
+    case, one, tb, batch, fx = _model_and_batch("tiny_train")
+    two = _model_and_batch("tiny_train")[1]
+    one.train(); two.train()
+    one.invariant_interest_model.two_streams = False
+    two.invariant_interest_model.two_streams = True
+    assert two.invariant_interest_model.uses_two_streams(10 ** 12) and not one.invariant_interest_model.uses_two_streams(1)
+    # forward + backward
+    outs, grads = [], []
+    for m in (one, two):
+        out = m(tb["x_history"], tb["x_target"], tb["x_global"])
+        loss = m.loss(tb["user_id"], out, tb["label"])
+        loss.backward()
+        torch.cuda.synchronize()
+        outs.append(out.detach().clone())
+        grads.append({k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+        for p in m.parameters():
+            p.grad = None
+        del out, loss                                        # no autograd graph of this model may outlive its step (capture below)
+    assert torch.equal(outs[0], outs[1])                     # the forward has no atomics at these sizes: bit-identical
+    assert grads[0].keys() == grads[1].keys()
+    for k in grads[0]:
+        scale = float(grads[0][k].abs().max()) + 1e-30
+        assert float((grads[0][k] - grads[1][k]).abs().max()) <= 1e-5 * scale, k
+    # three optimizer steps
+    oopt, topt = trainer.FlatAdam(one), trainer.FlatAdam(two)
+    if graphed:
+        for _ in range(3 + 3):
+            lo, _ = trainer.train_step(one, oopt, tb)
+        step = trainer.GraphedTrainStep(two, topt, tb, warmup=3)
+        for _ in range(3):
+            lt, _ = step.replay()
+    else:
+        for _ in range(3):
+            lo, _ = trainer.train_step(one, oopt, tb)
+            lt, _ = trainer.train_step(two, topt, tb)
+    torch.cuda.synchronize()
+    assert abs(float(lt) - float(lo)) < 1e-4 * abs(float(lo))
+    for (k, a), (_, b) in zip(one.named_parameters(), two.named_parameters()):
+        assert torch.allclose(a, b, rtol=0, atol=5e-4), k
