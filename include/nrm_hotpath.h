@@ -116,6 +116,16 @@ int nrm_gemm_tn(const float* A, int lda, int ncols_i, const float* B, int ldb, i
 int nrm_slab_reduce(const float* ws, int nsplit, int nj, int ldws, int ni, float* out, long out_istride, long out_jstride,
                     float* out2, long out2_istride, long out2_jstride, float sign2,
                     const float* vec, float* vec_out, nrm_stream_t stream);
+/* n slab sets in ONE launch (entries as the arguments of nrm_slab_reduce): the 14 reductions of a training step are small,
+ * latency-bound launches that depend on nothing but their own slabs, so a caller may defer them and flush them together
+ * before the optimizer reads the gradients (reference: autograd's per-parameter accumulation behind train.py:73). */
+typedef struct nrm_slab_desc {
+    const float* ws; int nsplit, nj, ldws, ni;
+    float* out; long out_istride, out_jstride;
+    float* out2; long out2_istride, out2_jstride; float sign2;
+    const float* vec; float* vec_out;
+} nrm_slab_desc;
+int nrm_slab_reduce_multi(const nrm_slab_desc* descs, int n, nrm_stream_t stream);
 
 /* ---- BatchNorm1d over rows (reference models/user_model.py:18,32), N % 4 == 0, ld % 4 == 0.
  * nrm_colreduce mode 0: s0 += sum_r x;  1: s0 += sum_r (x-mean)^2;  2: s0 += sum_r dy, s1 += sum_r dy*(x-mean)*rstd */

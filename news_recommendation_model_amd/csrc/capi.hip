@@ -3,6 +3,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <vector>
 
 #include "../../include/nrm_hotpath.h"
 #include "pwattn.hpp"
@@ -259,6 +260,23 @@ int nrm_slab_reduce(const float* ws, int nsplit, int nj, int ldws, int ni, float
     p.ws = ws; p.nsplit = nsplit; p.nj = nj; p.ldws = ldws; p.ni = ni; p.out = out; p.ors = out_istride; p.ocs = out_jstride;
     p.out2 = out2; p.ors2 = out2_istride; p.ocs2 = out2_jstride; p.sign2 = sign2; p.vec = vec; p.vec_out = vec_out;
     return check_hip(nrm::slab_reduce_launch(p, (hipStream_t)stream), "slab_reduce");
+}
+
+int nrm_slab_reduce_multi(const nrm_slab_desc* descs, int n, nrm_stream_t stream) {
+    if (n < 0 || (n > 0 && !descs)) return fail(NRM_EINVAL, "nrm_slab_reduce_multi: bad argument");
+    if (n == 0) return NRM_OK;
+    std::vector<nrm::SlabReduceParams> ps((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const nrm_slab_desc& d = descs[i];
+        if (!d.ws || !d.out) return fail(NRM_EINVAL, "nrm_slab_reduce_multi: entry %d: null pointer", i);
+        if (d.nsplit <= 0 || d.nj <= 0 || d.ni <= 0 || d.ldws < d.ni)
+            return fail(NRM_EINVAL, "nrm_slab_reduce_multi: entry %d: nsplit=%d nj=%d ni=%d ldws=%d", i, d.nsplit, d.nj, d.ni, d.ldws);
+        if ((d.vec == nullptr) != (d.vec_out == nullptr)) return fail(NRM_EINVAL, "nrm_slab_reduce_multi: entry %d: vec and vec_out go together", i);
+        nrm::SlabReduceParams& p = ps[(size_t)i];
+        p.ws = d.ws; p.nsplit = d.nsplit; p.nj = d.nj; p.ldws = d.ldws; p.ni = d.ni; p.out = d.out; p.ors = d.out_istride; p.ocs = d.out_jstride;
+        p.out2 = d.out2; p.ors2 = d.out2_istride; p.ocs2 = d.out2_jstride; p.sign2 = d.sign2; p.vec = d.vec; p.vec_out = d.vec_out;
+    }
+    return check_hip(nrm::slab_reduce_multi_launch(ps.data(), n, (hipStream_t)stream), "slab_reduce_multi");
 }
 
 // ------------------------------------------------------------------------------------------- BatchNorm

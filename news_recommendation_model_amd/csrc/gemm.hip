@@ -405,14 +405,14 @@ hipError_t gemm_tn_launch(GemmTnParams p, const GemmTnPlan& pl, hipStream_t st) 
 // 200 MB slab set (324 splits of 400 x 400 at C3) is streamed by thousands of blocks: reads run along i (the slab's fast
 // index), the partial tile is transposed through LDS and ADDED to the output along j with float atomics (the caller
 // zero-initialises `out`; one add per element and split chunk).  blockIdx.y == gridDim.y - 1 sums the bias vectors.
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceParams p, int spc) {
+__device__ __forceinline__ void slab_reduce_block(const SlabReduceParams& p, int spc, int bx, int by, int nby,
+                                                  float (*tile)[129]) {
     // tile = 128 (i, the slab's fast index: one float4 per thread and row) x 32 (j); LDS row stride 129: conflict-free both ways
-    __shared__ float tile[32][129];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int nbi = (p.ni + 127) / 128;
-    if (blockIdx.y == gridDim.y - 1) {                                 // vector leg (db = sum of per-split column sums)
+    if (by == nby - 1) {                                               // vector leg (db = sum of per-split column sums)
         if (!p.vec) return;
-        const int i = blockIdx.x * 256 + ty * 32 + tx;
+        const int i = bx * 256 + ty * 32 + tx;
         if (i < p.ni) {
             float a = 0.f;
             for (int s = 0; s < p.nsplit; ++s) a += p.vec[(size_t)s * p.ldws + i];
@@ -420,9 +420,9 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceParams
         }
         return;
     }
-    if ((int)blockIdx.x >= nbi * ((p.nj + 31) / 32)) return;            // grid.x is sized for the longer of the two legs
-    const int i0 = (blockIdx.x % nbi) * 128, j0 = (blockIdx.x / nbi) * 32;
-    const int s_lo = blockIdx.y * spc, s_hi = min(p.nsplit, s_lo + spc);
+    if (bx >= nbi * ((p.nj + 31) / 32)) return;                        // grid.x is sized for the longer of the two legs
+    const int i0 = (bx % nbi) * 128, j0 = (bx / nbi) * 32;
+    const int s_lo = by * spc, s_hi = min(p.nsplit, s_lo + spc);
     const size_t slab = (size_t)p.nj * p.ldws;
     f32x4 a[4];
 #pragma unroll
@@ -454,20 +454,59 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceParams
     }
 }
 
-hipError_t slab_reduce_launch(const SlabReduceParams& p, hipStream_t st) {
-    if (p.ni <= 0 || p.nj <= 0) return hipSuccess;
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceParams p, int spc) {
+    __shared__ float tile[32][129];
+    slab_reduce_block(p, spc, blockIdx.x, blockIdx.y, gridDim.y, tile);
+}
+
+// Several slab sets in ONE launch (blockIdx.z = set; the table travels in the kernel arguments): a training step's 14
+// reductions are small, latency-bound launches (20-75 us each whatever their size: 0.6 ms of a 2.1 ms step at the reference's
+// default sizes) that have nothing to wait for but their own slabs, so the host side defers them and flushes them together
+// before the optimizer reads the gradients (ops.flush_slab_reductions).
+__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const SlabTable tab) {
+    __shared__ float tile[32][129];
+    const int e = blockIdx.z;
+    if ((int)blockIdx.x >= tab.gx[e] || (int)blockIdx.y > tab.nchunk[e]) return;
+    slab_reduce_block(tab.e[e], tab.spc[e], blockIdx.x, blockIdx.y, tab.nchunk[e] + 1, tile);
+}
+
+static void slab_plan(const SlabReduceParams& p, int& gx, int& nchunk, int& spc) {
     const int nbi = (p.ni + 127) / 128, nbj = (p.nj + 31) / 32;
     const int tiles = nbi * nbj;
-    int gx = tiles;
+    gx = tiles;
     if (p.vec && (p.ni + 255) / 256 > gx) gx = (p.ni + 255) / 256;
-    int nchunk = 4096 / tiles;                                          // ~4096 blocks over the chip ...
+    nchunk = 4096 / tiles;                                              // ~4096 blocks over the chip ...
     if (nchunk > 32) nchunk = 32;                                       // ... but at most 32 atomic adds per output element
     if (nchunk > (p.nsplit + 3) / 4) nchunk = (p.nsplit + 3) / 4;       // (64 x 64 gradients come in 500+ slabs) and >= 4 slabs per block
     if (nchunk < 1) nchunk = 1;
-    const int spc = (p.nsplit + nchunk - 1) / nchunk;
+    spc = (p.nsplit + nchunk - 1) / nchunk;
     nchunk = (p.nsplit + spc - 1) / spc;
+}
+
+hipError_t slab_reduce_launch(const SlabReduceParams& p, hipStream_t st) {
+    if (p.ni <= 0 || p.nj <= 0) return hipSuccess;
+    int gx, nchunk, spc;
+    slab_plan(p, gx, nchunk, spc);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx, nchunk + 1), dim3(32, 8), 0, st, p, spc);
     return hipGetLastError();
+}
+
+hipError_t slab_reduce_multi_launch(const SlabReduceParams* ps, int n, hipStream_t st) {
+    for (int base = 0; base < n; base += SLAB_MAX) {
+        SlabTable tab;
+        const int m = n - base < SLAB_MAX ? n - base : SLAB_MAX;
+        int gx_max = 1, gy_max = 1;
+        for (int e = 0; e < m; ++e) {
+            tab.e[e] = ps[base + e];
+            slab_plan(tab.e[e], tab.gx[e], tab.nchunk[e], tab.spc[e]);
+            if (tab.gx[e] > gx_max) gx_max = tab.gx[e];
+            if (tab.nchunk[e] + 1 > gy_max) gy_max = tab.nchunk[e] + 1;
+        }
+        hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(gx_max, gy_max, m), dim3(32, 8), 0, st, tab);
+        const hipError_t err = hipGetLastError();
+        if (err != hipSuccess) return err;
+    }
+    return hipSuccess;
 }
 
 }  // namespace nrm

@@ -36,6 +36,7 @@ SIGNATURES = {
     "nrm_gemm_tn_nsplit": (_c_i, [_c_i, _c_i, _c_i]),
     "nrm_gemm_tn": (_c_i, [_c_fp, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_fp, _c_l, _c_fp]),
     "nrm_gemm_pack_multi": (_c_i, [_c_fp, _c_i, _c_fp]),
+    "nrm_slab_reduce_multi": (_c_i, [_c_fp, _c_i, _c_fp]),
     "nrm_colreduce": (_c_i, [_c_i] + [_c_fp] * 6 + [_c_i] * 3 + [_c_fp]),
     "nrm_bn_apply": (_c_i, [_c_fp] * 6 + [_c_i] * 3 + [_c_fp]),
     "nrm_bn_backward": (_c_i, [_c_fp] * 9 + [_c_i] * 4 + [_c_fp]),
@@ -61,6 +62,14 @@ class PackDesc(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("src2", ctypes.c_void_p), ("sign2", ctypes.c_float),
                 ("row_stride", ctypes.c_long), ("col_stride", ctypes.c_long), ("nrows", ctypes.c_int), ("ncols", ctypes.c_int),
                 ("packed", ctypes.c_void_p)]
+
+
+class SlabDesc(ctypes.Structure):
+    """nrm_slab_desc of include/nrm_hotpath.h"""
+    _fields_ = [("ws", ctypes.c_void_p), ("nsplit", ctypes.c_int), ("nj", ctypes.c_int), ("ldws", ctypes.c_int), ("ni", ctypes.c_int),
+                ("out", ctypes.c_void_p), ("out_istride", ctypes.c_long), ("out_jstride", ctypes.c_long),
+                ("out2", ctypes.c_void_p), ("out2_istride", ctypes.c_long), ("out2_jstride", ctypes.c_long), ("sign2", ctypes.c_float),
+                ("vec", ctypes.c_void_p), ("vec_out", ctypes.c_void_p)]
 
 
 _lib = None

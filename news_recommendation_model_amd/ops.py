@@ -213,9 +213,57 @@ def _gemm_tn_slabs(a, b, want_colsum, zero_out=None):
     return ws, cs, nsplit, ldws
 
 
+# Deferred slab reductions.  Inside ``with deferred_slab_reductions():`` a slab reduction is only recorded and ALL recorded
+# ones run as ONE nrm_slab_reduce_multi launch at flush_slab_reductions() -- the gradients they produce are not valid before
+# that.  trainer.train_step wraps backward() in it and FlatAdam.collect_grads flushes: nothing reads a weight gradient in
+# between, and 14 latency-bound launches per step become one.  Outside the context (any other caller of backward()) every
+# reduction runs at once, as before.
+# A record keeps the slabs alive and, of the DESTINATION tensors, only their storages: autograd's AccumulateGrad adopts a
+# gradient tensor without a copy only while nobody else references the tensor (a reference to it here made AccumulateGrad
+# clone the not-yet-reduced buffer); a reference to the storage keeps the memory valid without counting as one.
+_deferred = {"on": False, "pending": []}
+
+
+class deferred_slab_reductions:
+    def __enter__(self):
+        self.prev, _deferred["on"] = _deferred["on"], True
+        return self
+
+    def __exit__(self, *exc):
+        _deferred["on"] = self.prev
+        if exc[0] is not None:                       # a failed backward: drop what was recorded, its outputs are abandoned
+            _deferred["pending"].clear()
+        return False
+
+
+def flush_slab_reductions():
+    """Run every recorded slab reduction (one launch on the current stream); no-op when nothing is pending."""
+    pend, _deferred["pending"] = _deferred["pending"], []
+    if not pend:
+        return
+    descs = (native.SlabDesc * len(pend))()
+    for d, rec in zip(descs, pend):
+        d.ws, d.nsplit, d.nj, d.ldws, d.ni = rec["ws"].data_ptr(), rec["nsplit"], rec["nj"], rec["ldws"], rec["ni"]
+        d.out, d.out_istride, d.out_jstride = rec["out"], rec["out_is"], rec["out_js"]
+        d.out2, d.out2_istride, d.out2_jstride, d.sign2 = rec["out2"], rec["out2_is"], rec["out2_js"], rec["sign2"]
+        if rec["vec"] is not None:
+            d.vec, d.vec_out = rec["vec"].data_ptr(), rec["vec_out"]
+    native.call("nrm_slab_reduce_multi", descs, len(pend), native.stream_ptr())
+
+
 def _slab_reduce(ws, nsplit, nj, ldws, ni, out, out_is, out_js, out2=None, out2_is=0, out2_js=0, sign2=0.0,
                  vec=None, vec_out=None):
     """out (+)= sum over the split slabs (float atomics: ``out`` / ``out2`` must be zero-initialised)."""
+    if _deferred["on"]:
+        # (slabs recorded on the second attention's stream need no allocator bookkeeping: that stream waits for the main
+        # one before it is given new work, i.e. after the flush that read them)
+        _deferred["pending"].append(dict(
+            ws=ws, nsplit=nsplit, nj=nj, ldws=ldws, ni=ni, out=out.data_ptr(), out_is=out_is, out_js=out_js,
+            out2=out2.data_ptr() if out2 is not None else None, out2_is=out2_is, out2_js=out2_js, sign2=float(sign2),
+            vec=vec, vec_out=vec_out.data_ptr() if vec_out is not None else None,
+            keep=(out.untyped_storage(), out2.untyped_storage() if out2 is not None else None,
+                  vec_out.untyped_storage() if vec_out is not None else None)))
+        return
     native.call("nrm_slab_reduce", native.ptr(ws), nsplit, nj, ldws, ni, native.ptr(out), out_is, out_js,
                 native.ptr(out2) if out2 is not None else None, out2_is, out2_js, float(sign2),
                 native.ptr(vec) if vec is not None else None, native.ptr(vec_out) if vec_out is not None else None,

@@ -106,7 +106,8 @@ class FlatAdam:
         gradient tensors are released.  Idempotent until the next ``step()`` / ``zero_grad()``."""
         if self._collected:
             return
-        from . import native
+        from . import native, ops
+        ops.flush_slab_reductions()                # weight gradients whose slab reduction train_step deferred become valid here
         keep = []
         for i, p in enumerate(self.params):
             g = p.grad
@@ -195,11 +196,16 @@ def train_step(model, optimizer, batch, reducer: FlatGradReducer | None = None, 
     """One step of train.py:69-75 on device-resident tensors; returns (loss, out) detached."""
     out = model(batch["x_history"], batch["x_target"], batch["x_global"])
     loss = model.loss(batch["user_id"], out, batch["label"], alpha)
-    loss.backward()
     if isinstance(optimizer, FlatAdam):
+        from . import ops
+        # nobody reads a weight gradient between backward() and collect_grads(): the step's slab reductions (one per weight
+        # gradient) are recorded during backward and run as ONE launch when FlatAdam gathers the gradients
+        with ops.deferred_slab_reductions():
+            loss.backward()
         optimizer.all_reduce_grads()
         optimizer.step(zero_grad=True)                # Adam + zero_grad fused in one launch
     else:
+        loss.backward()
         if reducer is not None:
             reducer.reduce()
         optimizer.step()

@@ -136,3 +136,69 @@ def test_packed_weight_cache_follows_the_weights(lib):
     lin.load_state_dict({"weight": torch.ones(10, 24), "bias": torch.zeros(10)})
     y, n = run()
     assert n == 1 and torch.allclose(y, ref(), atol=1e-5)
+
+
+def test_slab_reduce_multi_matches_single_launches_and_numpy(lib):
+    """nrm_slab_reduce_multi: several slab sets (different shapes, strided destinations, a second signed destination, bias
+    vectors) in one launch == the same sets through nrm_slab_reduce one by one == numpy; and ops' deferred mode records
+    inside the context and produces the same gradients at the flush."""
+    from news_recommendation_model_amd import native, ops
+    rng = np.random.default_rng(3)
+    sets = []
+    for (nsplit, ni, nj, wide, second, vec) in [(5, 64, 64, 0, False, True), (37, 130, 33, 0, False, False), (160, 400, 400, 1600, True, True),
+                                                (1, 7, 5, 0, False, True), (600, 64, 64, 256, True, False), (20, 402, 1608, 0, False, True)] * 5:
+        ldws = (ni + 3) // 4 * 4
+        ws = rng.standard_normal((nsplit, nj, ldws)).astype(np.float32)
+        cs = rng.standard_normal((nsplit, ldws)).astype(np.float32) if vec else None
+        sets.append((nsplit, ni, nj, ldws, wide, second, ws, cs))
+    assert len(sets) > 24                                   # more than one table of the multi launch
+
+    def run(mode):
+        outs = []
+        descs = (native.SlabDesc * len(sets))()
+        keep = []
+        for d, (nsplit, ni, nj, ldws, wide, second, ws, cs) in zip(descs, sets):
+            w = torch.from_numpy(ws).cuda()
+            ld = wide if wide else nj
+            out = torch.zeros(ni, ld, device="cuda")
+            o2 = out[:, nj:] if second else None                # a second column block of the same wide matrix
+            v = torch.from_numpy(cs).cuda() if cs is not None else None
+            vo = torch.empty(ni, device="cuda") if cs is not None else None
+            keep.append((w, out, v, vo))
+            if mode == "single":
+                ops._slab_reduce(w, nsplit, nj, ldws, ni, out, ld, 1, out2=o2, out2_is=ld, out2_js=1, sign2=-1.0, vec=v, vec_out=vo)
+            elif mode == "deferred":
+                with ops.deferred_slab_reductions():
+                    ops._slab_reduce(w, nsplit, nj, ldws, ni, out, ld, 1, out2=o2, out2_is=ld, out2_js=1, sign2=-1.0, vec=v, vec_out=vo)
+            else:
+                d.ws, d.nsplit, d.nj, d.ldws, d.ni = w.data_ptr(), nsplit, nj, ldws, ni
+                d.out, d.out_istride, d.out_jstride = out.data_ptr(), ld, 1
+                d.out2 = o2.data_ptr() if o2 is not None else None
+                d.out2_istride, d.out2_jstride, d.sign2 = ld, 1, -1.0
+                d.vec = v.data_ptr() if v is not None else None
+                d.vec_out = vo.data_ptr() if vo is not None else None
+            outs.append((out, vo))
+        if mode == "deferred":
+            assert len(ops._deferred["pending"]) == len(sets)
+            assert float(outs[0][0].abs().max()) == 0.0      # recorded, not run
+            ops.flush_slab_reductions()
+            assert not ops._deferred["pending"]
+        elif mode == "multi":
+            native.call("nrm_slab_reduce_multi", descs, len(sets), native.stream_ptr())
+        torch.cuda.synchronize()
+        return [(o.cpu().numpy(), None if v is None else v.cpu().numpy()) for o, v in outs]
+
+    single, multi, deferred = run("single"), run("multi"), run("deferred")
+    for (nsplit, ni, nj, ldws, wide, second, ws, cs), (o1, v1), (o2, v2), (o3, v3) in zip(sets, single, multi, deferred):
+        ref = ws.astype(np.float64).sum(0)[:, :ni].T          # [ni, nj]
+        scale = np.abs(ref).max() + 1e-30
+        for o in (o1, o2, o3):
+            assert np.abs(o[:, :nj] - ref).max() <= 2e-6 * scale * max(1, nsplit) ** 0.5
+            if second:
+                assert np.abs(o[:, nj:2 * nj] + ref).max() <= 2e-6 * scale * max(1, nsplit) ** 0.5
+            if wide:
+                assert np.abs(o[:, (2 if second else 1) * nj:]).max() == 0.0      # nothing written outside the blocks
+        if cs is not None:
+            vref = cs.astype(np.float64).sum(0)[:ni]
+            for v in (v1, v2, v3):
+                assert np.abs(v - vref).max() <= 2e-6 * (np.abs(vref).max() + 1e-30) * max(1, nsplit) ** 0.5
