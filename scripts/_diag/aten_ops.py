@@ -13,7 +13,7 @@ from news_recommendation_model_amd.config import Dims, WORKLOADS
 
 wl = WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "C1-demo"]
 dims = Dims.for_emb(wl["emb"])
-B = min(wl["B"], 64)
+B = min(wl["B"], int(sys.argv[2]) if len(sys.argv) > 2 else 64)
 batch = synth.make_batch(dims, B, wl["H"], wl["T"], seed=0, dtype=np.float32)
 sd = synth.make_state_dict(dims, seed=1, user_num=int(batch["user_num"]), perturb=False)
 model = trainer.build_model(dims, int(batch["user_num"]), sd).train()
@@ -22,12 +22,11 @@ tb = trainer.batch_to_device(batch)
 for _ in range(3):
     trainer.train_step(model, opt, tb)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     trainer.train_step(model, opt, tb)
     torch.cuda.synchronize()
-rows = [e for e in prof.key_averages(group_by_stack_n=12) if e.key.startswith("aten::") and e.device_time_total > 0
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and e.device_time_total > 0
         and e.key in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::add", "aten::fill_", "aten::mul", "aten::sum", "aten::_to_copy")]
 rows.sort(key=lambda e: (e.key, -e.count))
 for e in rows:
-    st = [s for s in e.stack if "news_recommendation_model_amd" in s][:3]
-    print(f"{e.count:4d} {e.key:20s} dev_us={e.device_time_total:7.1f}  {' <- '.join(s.split('news_recommendation_model_amd/')[-1][:60] for s in st) or '(autograd engine)'}")
+    print(f"{e.count:4d} {e.key:20s} dev_us={e.device_time_total:7.1f}  shapes={e.input_shapes}")
