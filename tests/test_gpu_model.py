@@ -474,3 +474,32 @@ def test_two_stream_attention_branches_match_one_stream(lib, monkeypatch, graphe
     assert abs(float(lt) - float(lo)) < 1e-4 * abs(float(lo))
     for (k, a), (_, b) in zip(one.named_parameters(), two.named_parameters()):
         assert torch.allclose(a, b, rtol=0, atol=5e-4), k
+
+
+def test_deferred_slab_reductions_with_a_frozen_weight(lib):
+    """trainer.train_step defers the weight-gradient slab reductions to FlatAdam.collect_grads (one launch).  A weight that
+    takes no gradient has its (dropped) gradient buffer kept alive by the record and reduced into harmlessly; every other
+    parameter must move exactly as in a model where the reductions run at once."""
+    from news_recommendation_model_amd import ops, trainer
+    case, a, tb, batch, fx = _model_and_batch("tiny_train")
+    b = _model_and_batch("tiny_train")[1]
+    a.train(); b.train()
+    for m in (a, b):
+        m.mlp.fc1.weight.requires_grad_(False)
+        m.invariant_interest_model.label_attention.mlp.fc1.weight.requires_grad_(False)
+    aopt, bopt = trainer.FlatAdam(a), trainer.FlatAdam(b)
+    assert len(aopt.params) == len(list(a.parameters())) - 2
+    before = a.mlp.fc1.weight.detach().clone()
+    for _ in range(3):
+        la, _ = trainer.train_step(a, aopt, tb)                      # deferred (inside train_step)
+        out = b(tb["x_history"], tb["x_target"], tb["x_global"])     # immediate: a plain backward(), then the same optimizer
+        lb = b.loss(tb["user_id"], out, tb["label"])
+        lb.backward()
+        assert not ops._deferred["pending"]
+        bopt.step()
+    torch.cuda.synchronize()
+    assert not ops._deferred["pending"]
+    assert torch.equal(a.mlp.fc1.weight, before)                     # frozen stays frozen
+    assert abs(float(la) - float(lb)) < 1e-5 * abs(float(lb))
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.allclose(pa, pb, rtol=0, atol=2e-5), k
