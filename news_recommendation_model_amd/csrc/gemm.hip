@@ -242,6 +242,18 @@ static hipError_t launch_nt(const GemmNtParams& p, const GemmNtPlan& pl, int epi
 
 hipError_t gemm_nt_launch(const GemmNtParams& p, const GemmNtPlan& pl, int epi, hipStream_t st) {
     if (p.M <= 0) return hipSuccess;
+    // The row-tile count MT of a workgroup (64*MT rows) is free at launch time (the packed operand depends on NT only).  A grid
+    // of fewer than two workgroups per CU leaves every workgroup alone with its chain of K-chunk rounds (DMA, barrier, a few
+    // hundred MFMA cycles): C2's 258-wide layers were 240 workgroups of 128 rows at 57 % of the MFMA peak.  Such launches
+    // take one row tile per wave instead.  NRM_NT_SMALLM=0 keeps the planned MT.
+    static const bool small_m = [] { const char* e = getenv("NRM_NT_SMALLM"); return !(e && e[0] == '0'); }();
+    const long wgs = (long)((p.M + 64 * pl.MT - 1) / (64 * pl.MT)) * pl.nchunks;
+    if (small_m && pl.MT > 1 && wgs < 512) {
+        if (pl.NT == 4) return launch_nt<4, 1, 4>(p, pl, epi, st);
+        if (pl.NT == 5) return launch_nt<5, 1, 4>(p, pl, epi, st);
+        if (pl.NT == 8) return launch_nt<8, 1, 4>(p, pl, epi, st);
+        if (pl.NT == 9) return launch_nt<9, 1, 4>(p, pl, epi, st);
+    }
     if (pl.NT == 4) return launch_nt<4, 4>(p, pl, epi, st);
     if (pl.NT == 5) return launch_nt<5, 4>(p, pl, epi, st);
     if (pl.NT == 8) return launch_nt<8, 3>(p, pl, epi, st);
