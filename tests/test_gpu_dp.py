@@ -103,3 +103,32 @@ def test_bench_one_rank_through_rccl(lib, tmp_path):
     assert pr2.returncode == 0, pr2.stderr.decode(errors="replace")[-3000:]
     line2 = json.loads([ln for ln in pr2.stdout.decode().splitlines() if ln.startswith("{")][0])
     assert abs(line["loss"] - line2["loss"]) <= 1e-5 * max(1.0, abs(line2["loss"]))
+
+
+def test_bench_line_carries_the_contract_fields(lib, tmp_path):
+    """`python bench.py` (N = 1) prints ONE JSON line with the fields the driver and the judge read: metric / value / unit /
+    n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload, plus
+    `roofline` (bound, achieved, peak, unit, frac, traffic) and `cpu_baseline` (value, unit, cores, kind, sample).  Run on a
+    small shape with a short CPU sample; the numbers themselves are not judged here."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "NRM_DIST_BACKEND", "NRM_SINGLE_DEVICE", "NRM_DIST_WORLD1"):
+        env.pop(k, None)
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--workload", "ref-default",
+                         "--batch", "32", "--eager", "--cpu-seconds", "2"],
+                        env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+    assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in pr.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and "synthetic" in d["data"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 32 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]      # whole-job impressions per second
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and c["unit"] == d["unit"]
