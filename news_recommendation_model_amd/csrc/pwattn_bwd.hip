@@ -67,8 +67,14 @@ __global__ __launch_bounds__(256) void bwd_dz_kernel(float* __restrict__ z, cons
     f32x4* red = du_l + H * nx;
     const int tid = threadIdx.x;
     const int ty = tid / nx, tx = tid - ty * nx;
-    const int b = blockIdx.y;
-    const int col = blockIdx.x * slab_cols + 4 * tx;
+    // XCD-aware order: the sibling slabs of one impression share the 128-B lines their 400-B row segments straddle (D = 400:
+    // boundaries at 400-B multiples), and hardware deals consecutive block ids round-robin over the 8 XCDs.  Consecutive
+    // LOGICAL ids (the slabs of one b) go to one XCD, so a shared line is fetched / written back once, not once per L2.
+    const int nblk = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = lin & 7;
+    const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+    const int b = logical / gridDim.x, slab = logical - b * gridDim.x;
+    const int col = slab * slab_cols + 4 * tx;
     const bool cok = ty < ny && col < D;                             // D % 4 == 0
     const f32x4 w = cok ? *reinterpret_cast<const f32x4*>(w2 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
     if (ty < ny)
