@@ -168,8 +168,18 @@ __global__ __launch_bounds__(256) void bwd_dz_kernel(float* __restrict__ z, cons
 hipError_t bwd_dz_launch(float* z, const float* ds, const float* w2, float* dw2, float* du, float* dv,
                          int B, int T, int H, int D, hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    const int nslab = (D + 127) / 128;
-    const int slab_cols = ((D + nslab - 1) / nslab + 3) / 4 * 4;     // equal slabs (D = 400: 4 x 100 columns)
+    int nslab = (D + 127) / 128;
+    int slab_cols = ((D + nslab - 1) / nslab + 3) / 4 * 4;           // equal slabs (D = 400: 4 x 100 columns)
+    // Long histories: a candidate's rows fit ONE sweep of the workgroup (the path that requests the next candidate's rows before
+    // the arithmetic of the current one) only if H <= DZ_MAXIT * (256 / (slab_cols / 4)); narrower slabs give more row slots
+    // (reference default sizes, H = 200, D = 64: one 64-column slab has 80, four 16-column slabs 320 -- and 1024 workgroups
+    // instead of 256).  The sibling slabs share cache lines; the XCD-aware block order keeps them on one L2.
+    static const bool narrow = [] { const char* e = getenv("NRM_DZ_NARROW"); return !(e && e[0] == '0'); }();
+    while (narrow && slab_cols > 16 && H > DZ_MAXIT * (256 / (slab_cols / 4)) && H <= 256) {
+        nslab *= 2;
+        slab_cols = ((D + nslab - 1) / nslab + 3) / 4 * 4;
+        if (slab_cols < 16) slab_cols = 16;
+    }
     const int hchunk = H <= 256 ? H : 256;                           // history rows whose du slab shares the LDS
     const int nhc = (H + hchunk - 1) / hchunk;
     const size_t shm = ((size_t)hchunk * (slab_cols / 4) + 2 * 256) * sizeof(f32x4);
