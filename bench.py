@@ -332,6 +332,8 @@ def main():
             loss, _ = trainer.train_step(model, opt, tb, reducer)
         sync()
     elapsed = time.perf_counter() - t0
+    from news_recommendation_model_amd import ops as _ops
+    _ops.check_index_errors(dev)               # a clamped table index / user id would make the number meaningless: fail loudly
     if not (args.graph or args.no_kernel_timing):
         events, native.kernel_events, native.kernel_event_tags = native.kernel_events, None, None
         # heavy kernels: timed region; everything else: the 3 bracketed warm-up steps

@@ -66,6 +66,7 @@ def validate(models, batches):
         auc_sum += auc.double().sum()
         hit_sum += top1.double().sum()
         n += scores.shape[0]
+    ops.check_index_errors("cuda")               # an out-of-range table index in any batch (the reference raises IndexError)
     return [float(auc_sum / n), float(hit_sum / n)]
 
 

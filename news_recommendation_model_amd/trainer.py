@@ -337,7 +337,7 @@ def train_epochs(model, optimizer, make_loader, epochs, device="cuda", ckpt_path
     host sklearn loop), and saves the state_dict without ``delta`` (:95-97).  The reference never steps its scheduler
     (:99-100), so none is taken here.  Batches are staged through ``BatchPrefetcher``.
     Returns one dict per epoch: lr, loss_avg, auc_avg, impressions."""
-    from . import evaluation
+    from . import evaluation, ops
     history = []
     for epoch in range(epochs):
         model.train()                                                  # :56
@@ -360,6 +360,9 @@ def train_epochs(model, optimizer, make_loader, epochs, device="cuda", ckpt_path
                 on_batch(epoch, i, loss, auc)
         if int(bad_rows):                                               # checked once per epoch: no per-batch host sync
             raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
+        # an out-of-range table index / user id anywhere in the epoch: the reference raises IndexError at the offending batch
+        # (F.embedding, delta[id]); the kernels clamp, flag and go on, and the flag is read here, at the epoch's one host sync
+        ops.check_index_errors(device)
         rec = {"epoch": epoch, "lr": lr, "impressions": seen,
                "loss_avg": float(loss_sum / max(seen, 1)), "auc_avg": float(auc_sum / max(seen, 1))}
         history.append(rec)

@@ -100,3 +100,23 @@ def test_train_epochs_mirrors_the_reference_loop(lib, tmp_path):
     evaluation.load_checkpoint(fresh, tmp_path / "ckpt_epoch_7.pth")
     auc, hit = evaluation.validate([fresh], (trainer.batch_to_device(h, "cuda") for h in hosts))
     assert auc > 0.9
+
+
+def test_train_epochs_raises_indexerror_for_an_out_of_range_id(lib):
+    """The reference raises IndexError at the batch that holds an out-of-range category id (F.embedding); the kernels clamp
+    and flag, and trainer.train_epochs turns the flag into IndexError at the end of that epoch -- a loop cannot train on
+    clamped ids silently."""
+    from news_recommendation_model_amd import config, ops, synth, trainer
+    dims = config.Dims.for_emb(32, 60)
+    B, H, T, user_num = 8, 4, 3, 20
+    hosts = [synth.make_batch(dims, B, H, T, seed=700 + i, user_num=user_num) for i in range(2)]
+    cat_col = 4 + dims.pca_vector
+    hosts[1]["x_history"][3, 2, cat_col] = dims.category_label_num + 5          # one bad id in the second batch
+    model = trainer.build_model(dims, user_num, synth.make_state_dict(dims, seed=9, user_num=user_num))
+    opt = trainer.FlatAdam(model)
+    ops.check_index_errors("cuda")
+    with pytest.raises(IndexError):
+        trainer.train_epochs(model, opt, lambda: iter(hosts), 1)
+    ops.check_index_errors("cuda")                                              # the flag is cleared by the raise
+    hosts[1]["x_history"][3, 2, cat_col] = 1
+    assert len(trainer.train_epochs(model, opt, lambda: iter(hosts), 1)) == 1
