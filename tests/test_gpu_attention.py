@@ -211,6 +211,30 @@ def test_full_size_linearity_property(lib):
     p = {"a.mlp.fc1.weight": w1.cpu(), "a.mlp.fc1.bias": b1.cpu(), "a.mlp.fc2.weight": w2.cpu(), "a.mlp.fc2.bias": b2.cpu()}
     ref = orc.pointwise_attention_scores(p, "a", t[idx].cpu(), h[idx].detach().cpu())[..., 0]
     assert rel_err(s.detach()[idx].cpu().numpy(), ref.numpy()) < FWD_TOL
+    # ... and the BACKWARD of the full-size launch against the oracle: the gradients w.r.t. the target and
+    # history rows of an impression depend on that impression only, so the oracle runs on the same 2 impressions
+    tq = t.clone().requires_grad_(True)
+    s = ops.pointwise_attention_scores(tq, h, w1, b1, w2, b2)
+    gt_full, gh_full = torch.autograd.grad(s, [tq, h], g)
+    t_c, h_c = t[idx].cpu().clone().requires_grad_(True), h[idx].detach().cpu().clone().requires_grad_(True)
+    s_c = orc.pointwise_attention_scores(p, "a", t_c, h_c)[..., 0]
+    (s_c * g[idx].cpu()).sum().backward()
+    assert rel_err(gt_full[idx].cpu().numpy(), t_c.grad.numpy()) < GRAD_TOL
+    assert rel_err(gh_full[idx].cpu().numpy(), h_c.grad.numpy()) < GRAD_TOL
+    # the weight gradients sum over impressions: full launch == sum of the launches over its two halves, and the oracle's
+    # weight gradients of 2 impressions == the HIP weight gradients of a launch over just those 2
+    wq = [x.clone().requires_grad_(True) for x in (w1, b1, w2, b2)]
+    gw_full = torch.autograd.grad(ops.pointwise_attention_scores(t, h.detach(), *wq), wq, g)
+    gw_lo = torch.autograd.grad(ops.pointwise_attention_scores(t[:512], h[:512].detach(), *wq), wq, g[:512])
+    gw_hi = torch.autograd.grad(ops.pointwise_attention_scores(t[512:], h[512:].detach(), *wq), wq, g[512:])
+    for a, lo_, hi_ in zip(gw_full, gw_lo, gw_hi):
+        assert rel_err(a.cpu().numpy(), (lo_ + hi_).cpu().numpy()) < 1e-4
+    gw_two = torch.autograd.grad(ops.pointwise_attention_scores(t[idx], h[idx].detach(), *wq), wq, g[idx])
+    pc = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    s_c = orc.pointwise_attention_scores(pc, "a", t[idx].cpu(), h[idx].detach().cpu())[..., 0]
+    (s_c * g[idx].cpu()).sum().backward()
+    for a, k in zip(gw_two, ("a.mlp.fc1.weight", "a.mlp.fc1.bias", "a.mlp.fc2.weight", "a.mlp.fc2.bias")):
+        assert rel_err(a.cpu().numpy().reshape(-1), pc[k].grad.numpy().reshape(-1)) < GRAD_TOL, k
 
 
 def test_full_size_c2_bf16x3_properties(lib):
