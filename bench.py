@@ -176,7 +176,7 @@ def fwd_auc_parity(dev, mma="f32", case_name="c3_large"):
         sys.path.pop(0)
 
 
-HEAVY = ("nrm_pwattn_fwd", "pwattn_bwd_e_bt", "pwattn_bwd_e_bh", "nrm_pwattn_bwd_dz")   # event-timed inside the timed region
+HEAVY = ("nrm_pwattn_fwd", "pwattn_bwd_e_bt", "pwattn_bwd_e_bh", "pwattn_bwd_rw_dtdh", "nrm_pwattn_bwd_dz")   # event-timed inside the timed region
 
 
 def self_launch(n):
@@ -378,7 +378,7 @@ def main():
     for tag, e0, e1 in events:
         per.setdefault(tag, []).append(e0.elapsed_time(e1))
     kern = {k: {"launches": len(v), "mean_ms": float(np.mean(v)), "total_ms": float(np.sum(v))} for k, v in per.items()}
-    heavy = {k: v for k, v in kern.items() if k in HEAVY[:3]}
+    heavy = {k: v for k, v in kern.items() if k in HEAVY[:4]}
     dom = max(heavy, key=lambda k: heavy[k]["total_ms"])
     flops_per_launch = 2.0 * B * T * H * D * D            # both attentions have width D in BASELINE shapes
     achieved = flops_per_launch / (heavy[dom]["mean_ms"] * 1e-3) / 1e12

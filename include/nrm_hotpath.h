@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define NRM_ABI_VERSION 2
+#define NRM_ABI_VERSION 3
 #define NRM_OK 0
 #define NRM_EINVAL (-1)   /* bad shape / alignment / null pointer */
 #define NRM_ELAUNCH (-2)  /* HIP launch error */
@@ -26,6 +26,10 @@ typedef void* nrm_stream_t;
 
 int nrm_abi_version(void);
 const char* nrm_last_error(void);
+/* 0 for a product build.  Non-zero: the library was compiled with one of the timing-diagnostic overrides of scripts/_diag
+ * (kernels with parts of their work removed: results are WRONG by construction); the Python binding refuses to load such a
+ * library unless NRM_ALLOW_DIAG_LIB=1. */
+int nrm_build_flags(void);
 
 /* ---- pointwise history attention: reference models/attention_model.py:52-97
  *      (PointwiseAttentionExpanded.forward), score[b,t,h] = fc2(GELU(fc1(cat[h,t,t-h,t*h]))).
@@ -57,8 +61,14 @@ int nrm_pwattn_fwd(const float* t, const float* h, const float* u, const float* 
  *   z <- dz = ds * w2 * gelu'(z) in place;  dw2[k] += sum ds*gelu(z)   (dw2 must be initialised)
  *   du[b,h,:] = sum_t dz[b,t,h,:]  (gradient of u)      dv[b,t,:] = sum_h dz[b,t,h,:]  (gradient of v)
  * ds [B,T,H]; du [B,H,D] and dv [B,T,D] are overwritten (histories longer than 256 rows are processed in chunks). */
+/* dz_format: how dz is left in z_inout.  NRM_DZ_F32: fp32.  NRM_DZ_HL4 (for the bf16 arithmetics): every aligned group of 4
+ * values as 4 bf16 hi + 4 bf16 lo (lo = bf16 of the rounding remainder) in the same 16 bytes -- the MFMA-ready operand that
+ * nrm_pwattn_bwd_rw_dtdh and the dW_p-only pass of nrm_pwattn_bwd_contract read without conversion (du, dv, dw2 are computed
+ * from the fp32 values either way). */
+#define NRM_DZ_F32 0
+#define NRM_DZ_HL4 1
 int nrm_pwattn_bwd_dz(float* z_inout, const float* ds, const float* w2, float* dw2, float* du, float* dv,
-                      int B, int T, int H, int D, nrm_stream_t stream);
+                      int B, int T, int H, int D, int dz_format, nrm_stream_t stream);
 /* number of [D,D] partial slabs nrm_pwattn_bwd_contract writes into `ws` (depends on the arithmetic: tile shapes differ) */
 int nrm_pwattn_bwd_nsplit(int B, int T, int H, int D, int mma);
 /* backward, step 2 (the bilinear term): given dz [B,T,H,D], t, h and W_p (row stride ldwp)
@@ -66,10 +76,21 @@ int nrm_pwattn_bwd_nsplit(int B, int T, int H, int D, int mma);
  *   ws[i][d][k] (i < nsplit) = partial of dW_p[k,d] = sum_{b,t,h} dz[b,t,h,k] t[b,t,d] h[b,h,d]
  *                              (TRANSPOSED slabs: sum them over i, then transpose)
  * dt/dh are accumulated into (float atomics), ws is overwritten.
- * passes: bit 0 = the (b,t)-grouped launch (dt, ws), bit 1 = the (b,h)-grouped launch (dh); 3 = both. */
+ * passes: bit 0 = the (b,t)-grouped launch (dt, ws), bit 1 = the (b,h)-grouped launch (dh); 3 = both.
+ * passes = 4 (bf16 arithmetics, dz in NRM_DZ_HL4): the (b,t)-grouped launch WITHOUT its dt epilogue -- only ws; dt and dh then
+ * come from nrm_pwattn_bwd_rw_dtdh.  dz_format names the layout of dz (NRM_DZ_F32 for passes 1..3). */
 int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, const float* wp, int ldwp,
                             float* dt, float* dh, float* ws,
-                            int B, int T, int H, int D, int passes, int mma, nrm_stream_t stream);
+                            int B, int T, int H, int D, int passes, int mma, int dz_format, nrm_stream_t stream);
+/* backward, step 2 in the "resident W_p" form (bf16 arithmetics, D <= 256): the same dt / dh as above from ONE contraction
+ * dP = dz W_p whose W_p image stays in LDS and whose dz operand (NRM_DZ_HL4) is read exactly once; autograd of
+ * models/attention_model.py:81-92 w.r.t. target and history.  nrm_pwattn_bwd_rw_supported: 1 if (D, mma) has this form;
+ * packed: nrm_pwattn_bwd_rw_packed_floats floats filled by nrm_pwattn_bwd_rw_pack from fc1_weight [D, 4D] (row stride ld). */
+int nrm_pwattn_bwd_rw_supported(int D, int mma);
+long nrm_pwattn_bwd_rw_packed_floats(int D, int mma);
+int nrm_pwattn_bwd_rw_pack(const float* fc1_weight, int ld, int D, int mma, float* packed, nrm_stream_t stream);
+int nrm_pwattn_bwd_rw_dtdh(const float* dz_hl4, const float* t, const float* h, const float* packed, float* dt, float* dh,
+                           int B, int T, int H, int D, int mma, nrm_stream_t stream);
 
 /* ---- dense layers: reference MLP.forward (models/attention_model.py:29-32: fc1 -> GELU -> fc2), the history
  *      projection w1 (models/user_invariant_interest_model.py:78) and the attention's side projections.

@@ -14,7 +14,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnrm_hotpath.so")
-SOURCES = ["pwattn_fwd.hip", "pwattn_fwd_rw.hip", "pwattn_bwd.hip", "gemm.hip", "head.hip", "pool_loss.hip", "frontend.hip", "capi.hip"]
+SOURCES = ["pwattn_fwd.hip", "pwattn_fwd_rw.hip", "pwattn_bwd.hip", "pwattn_bwd_rw.hip", "gemm.hip", "head.hip", "pool_loss.hip",
+           "frontend.hip", "capi.hip"]
+OBJDIR = os.path.join(HERE, "build")          # per-source objects (git-ignored): only changed sources are recompiled
 
 
 def _hipcc():
@@ -46,16 +48,37 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
-        return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB + ".tmp"]
+def build(force=False, verbose=True, extra_flags=(), lib=None):
+    """Compile every source to an object (in parallel, skipping objects newer than all sources and headers), then link.
+    ``extra_flags`` / ``lib``: the timing-diagnostic builds of scripts/_diag (their objects are not cached)."""
+    from concurrent.futures import ThreadPoolExecutor
+    out = lib or LIB
+    if not force and not extra_flags and not needs_build():
+        return out
+    hipcc = _hipcc()
+    objdir = OBJDIR if not extra_flags else OBJDIR + "_" + "".join(c if c.isalnum() else "_" for c in " ".join(extra_flags))
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [os.path.join(HERE, "..", "include", "nrm_hotpath.h")]
+    hdr_time = max(os.path.getmtime(h) for h in headers)
+
+    def compile_one(src):
+        path, obj = os.path.join(CSRC, src), os.path.join(objdir, src + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_time):
+            return obj
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *extra_flags, "-c", path, "-o", obj]
+        if verbose:
+            print("[nrm build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", out + ".tmp"]
     if verbose:
         print("[nrm build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":

@@ -51,6 +51,8 @@ static int check_dims(const char* fn, int B, int T, int H, int D) {
 extern "C" {
 
 int nrm_abi_version(void) { return NRM_ABI_VERSION; }
+int nrm_build_flags(void) { return nrm::pwattn_fwd_diag_flags() | nrm::pwattn_fwd_rw_diag_flags() | nrm::pwattn_bwd_diag_flags() |
+                                    nrm::pwattn_bwd_rw_diag_flags(); }
 const char* nrm_last_error(void) { return g_err; }
 
 long nrm_pwattn_packed_floats(int D) {
@@ -102,11 +104,35 @@ int nrm_pwattn_fwd(const float* t, const float* h, const float* u, const float* 
 }
 
 int nrm_pwattn_bwd_dz(float* z_inout, const float* ds, const float* w2, float* dw2, float* du, float* dv,
-                      int B, int T, int H, int D, nrm_stream_t stream) {
+                      int B, int T, int H, int D, int dz_format, nrm_stream_t stream) {
     if (int rc = check_dims("nrm_pwattn_bwd_dz", B, T, H, D)) return rc;
     if (!z_inout || !ds || !w2 || !dw2 || !du || !dv) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dz: null pointer");
     if (B > 65535) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dz: B=%d > 65535 (one grid row per impression)", B);
-    return check_hip(nrm::bwd_dz_launch(z_inout, ds, w2, dw2, du, dv, B, T, H, D, (hipStream_t)stream), "bwd_dz");
+    if (dz_format != NRM_DZ_F32 && dz_format != NRM_DZ_HL4) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dz: dz_format=%d (NRM_DZ_F32 or NRM_DZ_HL4)", dz_format);
+    return check_hip(nrm::bwd_dz_launch(z_inout, ds, w2, dw2, du, dv, B, T, H, D, dz_format, (hipStream_t)stream), "bwd_dz");
+}
+
+int nrm_pwattn_bwd_rw_supported(int D, int mma) { return nrm::pwattn_bwd_rw_plan(D, mma).ng ? 1 : 0; }
+long nrm_pwattn_bwd_rw_packed_floats(int D, int mma) { return nrm::pwattn_bwd_rw_packed_floats(D, mma); }
+
+int nrm_pwattn_bwd_rw_pack(const float* fc1_weight, int ld, int D, int mma, float* packed, nrm_stream_t stream) {
+    if (!fc1_weight || !packed) return fail(NRM_EINVAL, "nrm_pwattn_bwd_rw_pack: null pointer");
+    if (D <= 0 || D % 4 || ld < 4 * D) return fail(NRM_EINVAL, "nrm_pwattn_bwd_rw_pack: D=%d ld=%d (need D%%4==0, ld>=4D)", D, ld);
+    if (!nrm_pwattn_bwd_rw_supported(D, mma)) return fail(NRM_EINVAL, "nrm_pwattn_bwd_rw_pack: D=%d mma=%d has no resident-W backward", D, mma);
+    return check_hip(nrm::pwattn_bwd_rw_pack_launch(fc1_weight + 3 * (long)D, ld, D, mma, packed, (hipStream_t)stream), "bwd_rw_pack");
+}
+
+int nrm_pwattn_bwd_rw_dtdh(const float* dz_hl4, const float* t, const float* h, const float* packed, float* dt, float* dh,
+                           int B, int T, int H, int D, int mma, nrm_stream_t stream) {
+    if (int rc = check_dims("nrm_pwattn_bwd_rw_dtdh", B, T, H, D)) return rc;
+    if (!dz_hl4 || !t || !h || !packed || !dt || !dh) return fail(NRM_EINVAL, "nrm_pwattn_bwd_rw_dtdh: null pointer");
+    if (!nrm_pwattn_bwd_rw_supported(D, mma)) return fail(NRM_EINVAL, "nrm_pwattn_bwd_rw_dtdh: D=%d mma=%d has no resident-W backward", D, mma);
+    if ((long)T * H * D * 4 >= (1L << 31)) return fail(NRM_EINVAL, "nrm_pwattn_bwd_rw_dtdh: one impression's dz block exceeds 2^31 bytes");
+    if (B == 0) return NRM_OK;
+    nrm::BwdRwParams p = {};
+    p.dz = dz_hl4; p.t = t; p.h = h; p.wimg = packed; p.dt = dt; p.dh = dh; p.B = B; p.T = T; p.H = H; p.D = D;
+    p.w_bytes = (unsigned)(nrm_pwattn_bwd_rw_packed_floats(D, mma) * 4);
+    return check_hip(nrm::pwattn_bwd_rw_launch(p, mma, (hipStream_t)stream), "bwd_rw_dtdh");
 }
 
 int nrm_pwattn_bwd_nsplit(int B, int T, int H, int D, int mma) {
@@ -118,19 +144,23 @@ int nrm_pwattn_bwd_nsplit(int B, int T, int H, int D, int mma) {
 
 int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, const float* wp, int ldwp,
                             float* dt, float* dh, float* ws, int B, int T, int H, int D, int passes, int mma,
-                            nrm_stream_t stream) {
+                            int dz_format, nrm_stream_t stream) {
     if (int rc = check_dims("nrm_pwattn_bwd_contract", B, T, H, D)) return rc;
     if (int rc = check_mma("nrm_pwattn_bwd_contract", mma)) return rc;
 
     if (!dz || !t || !h || !wp) return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: null pointer");
-    if (passes < 1 || passes > 3) return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: passes=%d", passes);
-    if (((passes & 1) && (!dt || !ws)) || ((passes & 2) && !dh)) return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: null output");
+    if (passes != 1 && passes != 2 && passes != 3 && passes != 4) return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: passes=%d", passes);
+    if ((passes == 4) != (dz_format == NRM_DZ_HL4) || (dz_format != NRM_DZ_F32 && dz_format != NRM_DZ_HL4))
+        return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: passes=%d with dz_format=%d (the dW_p-only pass, 4, reads NRM_DZ_HL4; the others fp32)", passes, dz_format);
+    if (passes == 4 && mma == NRM_MMA_F32) return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: the dW_p-only pass exists for the bf16 arithmetics");
+    if (((passes & 1) && (!dt || !ws)) || ((passes & 2) && !dh) || (passes == 4 && !ws)) return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: null output");
     if (ldwp < D || ldwp % 4) return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: ldwp=%d", ldwp);
     if (B == 0) return NRM_OK;
     const long HD = (long)H * D, TD = (long)T * D;
     // pass 1: groups (b,t); rows r = h.  X_g = dz[b,t,:,:], Y_g = h[b];  out = dt, scale rows = t
-    if (passes & 1) {
+    if ((passes & 1) || passes == 4) {
         nrm::BwdEParams p = {};
+        p.with_dt = passes == 4 ? 0 : 1; p.x_hl4 = passes == 4 ? 1 : 0;
         p.X = dz; p.xs1 = (long)T * HD; p.xs2 = HD; p.xrs = D;
         p.Y = h; p.ys1 = HD; p.yrs = D;
         p.wp = wp; p.ldwp = ldwp; p.srow = t; p.lds_ = D; p.out = dt; p.ldo = D; p.ws = ws;
@@ -151,7 +181,7 @@ int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, con
         p.X = dz; p.xs1 = (long)T * HD; p.xs2 = D; p.xrs = HD;
         p.Y = t; p.ys1 = TD; p.yrs = D;
         p.wp = wp; p.ldwp = ldwp; p.srow = nullptr; p.lds_ = 0; p.out = dh; p.ldo = D; p.ws = nullptr;
-        p.G = B * H; p.G2 = H; p.R = T; p.D = D;
+        p.G = B * H; p.G2 = H; p.R = T; p.D = D; p.with_dt = 1;
         // this variant keeps no dW_p accumulators (<= 168 VGPRs): three waves per SIMD
         int tw = kBhWaves;
         if (const char* e = getenv("NRM_BH_WAVES")) tw = atoi(e);

@@ -48,11 +48,39 @@ struct BwdEParams {
     int nkw, ndcol;                       // k-ranges and d-columns of the wave-tile grid
     int nsplit;
     int interleave;                       // serial kernel: the 4 waves of a workgroup walk one group range round-robin
+    int x_hl4;                            // X is in the NRM_DZ_HL4 format (bf16 forms only): no conversion of the dz operand
+    int with_dt;                          // 0: the (b,t)-grouped pass only accumulates dW_p (dt comes from pwattn_bwd_rw.hip)
 };
 struct BwdEPlan { int DT, KT, ndcol, nkw, nsplit, gps; };
 BwdEPlan bwd_e_plan(int D, int G, int target_waves, int min_gps = 1, int mma = 0);
 hipError_t bwd_e_launch(const BwdEParams& p, const BwdEPlan& pl, bool with_dw, int mma, hipStream_t st);
+// dz_format: 0 = fp32 dz in place, 1 = NRM_DZ_HL4 (every aligned group of 4 values as 4 bf16 hi + 4 bf16 lo, in place)
 hipError_t bwd_dz_launch(float* z, const float* ds, const float* w2, float* dw2, float* du, float* dv,
-                         int B, int T, int H, int D, hipStream_t st);
+                         int B, int T, int H, int D, int dz_format, hipStream_t st);
+
+// ---- backward of the bilinear term, resident-W form for the bf16 arithmetics (pwattn_bwd_rw.hip): dt and dh from ONE read of dz
+struct BwdRwParams {
+    const float* dz;     // [B*T*H, D] in the NRM_DZ_HL4 format
+    const float* t;      // [B*T, D]
+    const float* h;      // [B*H, D]
+    const float* wimg;   // packed by pwattn_bwd_rw_pack_launch
+    float* dt;           // [B*T, D]  +=
+    float* dh;           // [B*H, D]  +=
+    int B, T, H, D;
+    unsigned w_bytes;
+    int tsplit;          // parts of the candidate walk (set by the launcher)
+};
+struct BwdRwPlan { int ng, kc, nks, wimg, k32, rows; };   // ng == 0: this (D, mma) keeps the E-form
+BwdRwPlan pwattn_bwd_rw_plan(int D, int mma);
+long pwattn_bwd_rw_packed_floats(int D, int mma);
+hipError_t pwattn_bwd_rw_pack_launch(const float* wp, int ldw, int D, int mma, float* packed, hipStream_t st);
+hipError_t pwattn_bwd_rw_launch(const BwdRwParams& p, int mma, hipStream_t st);
+
+// Non-zero when the translation unit was compiled with a timing-diagnostic override (scripts/_diag): such a library computes
+// WRONG results by construction; capi.hip ORs these into nrm_build_flags() and native.load refuses a non-zero value.
+int pwattn_fwd_diag_flags();        // pwattn_fwd.hip:     bit 0 NRM_DIAG_FWD, bit 1 XCD_REMAP off
+int pwattn_fwd_rw_diag_flags();     // pwattn_fwd_rw.hip:  bit 2 NRM_DIAG_RW
+int pwattn_bwd_rw_diag_flags();     // pwattn_bwd_rw.hip:  bit 9 NRM_DIAG_BRW
+int pwattn_bwd_diag_flags();        // pwattn_bwd.hip:     bits 3.. NRM_EPI_AHEAD off, GELU_AT_LOAD, NOEPI, NOATOM, NOLOAD, NRM_PIPE_SGB off
 
 }  // namespace nrm

@@ -55,7 +55,7 @@ constexpr int DZ_MAXIT = 5;      // history rows per thread and candidate held i
 __global__ __launch_bounds__(256) void bwd_dz_kernel(float* __restrict__ z, const float* __restrict__ ds,
                                                      const float* __restrict__ w2, float* __restrict__ dw2,
                                                      float* __restrict__ du, float* __restrict__ dv,
-                                                     int T, int Hall, int D, int slab_cols, int hchunk) {
+                                                     int T, int Hall, int D, int slab_cols, int hchunk, int fmt) {
     extern __shared__ __attribute__((aligned(16))) float sm[];       // [H][nx] du slab | 2 x [256] float4 exchange
     const int nx = slab_cols >> 2, ny = 256 / nx;
     // blockIdx.z = chunk of history rows [h0, h0 + H): one chunk unless the du slab of all rows would not fit the LDS
@@ -105,7 +105,23 @@ __global__ __launch_bounds__(256) void bwd_dz_kernel(float* __restrict__ z, cons
                     aw[e] = fmaf(g[u] * zz[u][e], gp.cdf, aw[e]);                          // ds * gelu(z)
                     dz[e] = g[u] * w[e] * fmaf(zz[u][e] * 0.39894228040143267794f, gp.e, gp.cdf);
                 }
-                *reinterpret_cast<f32x4*>(z + (row0 + h) * D + col) = dz;
+                if (fmt) {
+                    // NRM_DZ_HL4: the four values as 4 bf16 hi + 4 bf16 lo (lo = rounding remainder) in the same 16 bytes -- the
+                    // MFMA-ready operand of the bf16 contraction kernels (pwattn_bwd_rw.hip reads it without any conversion)
+                    unsigned short hi[4], lo[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const __bf16 hb = (__bf16)dz[e];
+                        const __bf16 lb = (__bf16)(dz[e] - (float)hb);
+                        hi[e] = __builtin_bit_cast(unsigned short, hb);
+                        lo[e] = __builtin_bit_cast(unsigned short, lb);
+                    }
+                    *reinterpret_cast<u32x4*>(z + (row0 + h) * D + col) =
+                        u32x4{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16),
+                              (unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16)};
+                } else {
+                    *reinterpret_cast<f32x4*>(z + (row0 + h) * D + col) = dz;
+                }
                 av += dz;
                 du_l[h * nx + tx] += dz;
             }
@@ -166,7 +182,7 @@ __global__ __launch_bounds__(256) void bwd_dz_kernel(float* __restrict__ z, cons
 }
 
 hipError_t bwd_dz_launch(float* z, const float* ds, const float* w2, float* dw2, float* du, float* dv,
-                         int B, int T, int H, int D, hipStream_t st) {
+                         int B, int T, int H, int D, int dz_format, hipStream_t st) {
     if (B <= 0) return hipSuccess;
     int nslab = (D + 127) / 128;
     int slab_cols = ((D + nslab - 1) / nslab + 3) / 4 * 4;           // equal slabs (D = 400: 4 x 100 columns)
@@ -193,7 +209,7 @@ hipError_t bwd_dz_launch(float* z, const float* ds, const float* w2, float* dw2,
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(bwd_dz_kernel, dim3((D + slab_cols - 1) / slab_cols, B, nhc), dim3(256), shm, st, z, ds, w2, dw2, du, dv,
-                       T, H, D, slab_cols, hchunk);
+                       T, H, D, slab_cols, hchunk, dz_format);
     return hipGetLastError();
 }
 
@@ -224,21 +240,26 @@ __device__ __forceinline__ int tile_pos(int c) { return c < 64 ? 16 * (c & 3) + 
 // is all a dot product needs.  Accumulators (E and dW_p), the epilogue and every reduction stay fp32.
 // MMA == 2 (NRM_MMA_BF16X3): both operands are split hi + lo (lo = the bf16 rounding remainder) and every product takes three
 // MFMAs (lo*hi + hi*lo + hi*hi): fp32-class accuracy at 3/16 of the fp32 MFMA time.
-template <int KT, int DT, int KS, bool WITH_DW, bool EXACT, int MMA = 0>
-__global__ __launch_bounds__(256, (MMA && KT > 4) || (MMA == 2 && WITH_DW) ? 1 : 2) void bwd_e_kernel(const BwdEParams p) {
+// WITH_DT = false (bf16 forms, WITH_DW): the pass only accumulates dW_p -- no W_p^T tile in LDS, no per-group out-row flush; dt
+// then comes from pwattn_bwd_rw.hip.  XHL4: X is stored in the NRM_DZ_HL4 format (bf16 hi/lo pairs written by the dz pass):
+// its MFMA operand is assembled with one v_perm_b32 per dword instead of a convert / subtract / convert per element.
+template <int KT, int DT, int KS, bool WITH_DW, bool EXACT, int MMA = 0, bool WITH_DT = true, bool XHL4 = false>
+__global__ __launch_bounds__(256, (MMA && KT > 4) || (MMA == 2 && WITH_DW && WITH_DT) ? 1 : 2) void bwd_e_kernel(const BwdEParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-descriptor builtins: device pass only (keeps the host stub)
     static_assert(KS == DT, "one pass over the whole d range per group (the 3+2 sub-pass split is gone)");
     constexpr bool BF16 = MMA != 0;
+    static_assert(WITH_DT || (WITH_DW && BF16), "the dW-only form exists for the bf16 arithmetics");
+    static_assert(!XHL4 || (BF16 && KT == 4), "hl4 operands: bf16 forms on 4x4 tiles");
     // epilogue with the W_p^T reads two tiles ahead (and step 1 of the next group requested after it): pays on 5x5 tiles
     // (C3: 4.57 -> 4.48 ms); on 4x4 tiles the serial one-read-one-FMA form is faster (C5, D = 768: 20.6 vs 23.2 ms)
     constexpr bool AHEAD = WITH_DW && NRM_EPI_AHEAD && !BF16 && KT == 5;
     constexpr int LDK = KT * 16 + 8;      // padded row of the W_p^T tile: +8 is conflict-free under gfx950 b128 lane groups (+4 is 2-way)
-    __shared__ __attribute__((aligned(16))) float smem[DT * 16 * LDK + 4 * DT * 16];
+    __shared__ __attribute__((aligned(16))) float smem[WITH_DT ? DT * 16 * LDK + 4 * DT * 16 : 4];
     float* wpt = smem;                                                  // [DT*16 d][LDK]  = W_p[k0+k][d0+d]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably uniform -> SGPR math below
-    float* bounce = smem + DT * 16 * LDK + wave * (DT * 16);           // wave-private
+    float* bounce = smem + (WITH_DT ? DT * 16 * LDK + wave * (DT * 16) : 0);   // wave-private
     const int r16 = lane & 15, q = lane >> 4;
     const int D = p.D, R = p.R;
 
@@ -257,6 +278,7 @@ __global__ __launch_bounds__(256, (MMA && KT > 4) || (MMA == 2 && WITH_DW) ? 1 :
     const int k0 = kw * (KT * 16);
 
     // ---- prologue: W_p^T tile -> LDS (zero padded), one barrier
+    if (WITH_DT) {
     for (int idx = tid; idx < KT * 16 * DT * 4; idx += 256) {
         const int kl = idx / (DT * 4), d4 = idx - kl * (DT * 4);
         const int k = k0 + kl, d = d0 + 4 * d4;
@@ -266,6 +288,7 @@ __global__ __launch_bounds__(256, (MMA && KT > 4) || (MMA == 2 && WITH_DW) ? 1 :
         for (int e = 0; e < 4; ++e) wpt[tile_pos(4 * d4 + e) * LDK + tile_pos(kl)] = w[e];
     }
     __syncthreads();
+    }
 
     const int split = sgrp * 4 + wave;
     if (split >= p.nsplit) return;
@@ -360,10 +383,27 @@ __global__ __launch_bounds__(256, (MMA && KT > 4) || (MMA == 2 && WITH_DW) ? 1 :
                 for (int jp = 0; jp < 4; ++jp) {
                     load_step(a0, b0, 8 * ss + 2 * jp);
                     load_step(a1, b1, 8 * ss + 2 * jp + 1);
+                    if (XHL4) {
+                        // a0 / a1 hold the raw hl4 units of rows 2jp / 2jp+1: dwords {hi01, hi23, lo01, lo23} of columns 4*r16 + {0..3};
+                        // tile it takes 16-bit half (it & 1) of dword (it >> 1): one v_perm_b32 joins the two rows' halves
+#pragma unroll
+                        for (int it = 0; it < KT; ++it) {
+                            const unsigned sel = (it & 1) ? 0x07060302u : 0x05040100u;
+                            const unsigned hw = __builtin_amdgcn_perm(__float_as_uint(a1[it >> 1]), __float_as_uint(a0[it >> 1]), sel);
+                            af[it][2 * jp] = __builtin_bit_cast(__bf16, (unsigned short)(hw & 0xffffu));
+                            af[it][2 * jp + 1] = __builtin_bit_cast(__bf16, (unsigned short)(hw >> 16));
+                            if (MMA == 2) {
+                                const unsigned lw = __builtin_amdgcn_perm(__float_as_uint(a1[2 + (it >> 1)]), __float_as_uint(a0[2 + (it >> 1)]), sel);
+                                al[it][2 * jp] = __builtin_bit_cast(__bf16, (unsigned short)(lw & 0xffffu));
+                                al[it][2 * jp + 1] = __builtin_bit_cast(__bf16, (unsigned short)(lw >> 16));
+                            }
+                        }
+                    } else {
 #pragma unroll
                     for (int it = 0; it < KT; ++it) {
                         af[it][2 * jp] = (__bf16)a0[it]; af[it][2 * jp + 1] = (__bf16)a1[it];
                         if (MMA == 2) { al[it][2 * jp] = (__bf16)(a0[it] - (float)af[it][2 * jp]); al[it][2 * jp + 1] = (__bf16)(a1[it] - (float)af[it][2 * jp + 1]); }
+                    }
                     }
 #pragma unroll
                     for (int jt = 0; jt < DT; ++jt) {
@@ -440,6 +480,13 @@ __global__ __launch_bounds__(256, (MMA && KT > 4) || (MMA == 2 && WITH_DW) ? 1 :
             if (keep == 123.456f) bounce[r16] = keep;
             return;
         }
+        if (!WITH_DT) {                                              // dW_p only: no k-reduction, no out row
+#pragma unroll
+            for (int jt = 0; jt < DT; ++jt)
+#pragma unroll
+                for (int it = 0; it < KT; ++it) dW[it][jt] += E[it][jt] * sr[jt];
+            return;
+        }
         if (AHEAD) {
             // flattened (jt, it) order, LDS reads two tiles ahead of their FMAs
             constexpr int NTILE = KT * DT;
@@ -503,6 +550,7 @@ __global__ __launch_bounds__(256, (MMA && KT > 4) || (MMA == 2 && WITH_DW) ? 1 :
         // k-partial of out[g, d0 .. d0+DT*16): one dword per lane, contiguous segments.
         // bounce[] is wave-private: LDS ops of one wave complete in order, the fences only pin hipcc.
         if (NRM_DIAG_NOEPI && g + g_step < g_hi) continue;
+        if (!WITH_DT) continue;
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         __builtin_amdgcn_wave_barrier();
         float* orow = p.out + (long)g * p.ldo + d0;
@@ -731,6 +779,130 @@ __global__ __launch_bounds__(256, 2) void bwd_e_pipe_kernel(const BwdEParams p) 
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// (2c) dW_p-only pass of the resident-W backward (pwattn_bwd_rw.hip) for groups of at most 32 rows (one 32-deep MFMA step per
+// group; C2: H = 32): the generic bf16 form above requests a group's operands, waits, converts and only then issues its 48 MFMAs
+// -- two thirds of its time is operand traffic (timing-only builds: 0.29 ms with, 0.10 ms without the loads at C2).  Here
+//   * Y_g (the history rows h[b]) depends on b only: its bf16 hi / lo fragments are built ONCE per impression and kept in
+//     registers across that impression's T groups (no reload, no conversion);
+//   * X_g (dz in the NRM_DZ_HL4 format) of group g + 1 is requested before the MFMAs of group g, into the registers whose raw
+//     units have just been assembled into fragments (one v_perm_b32 per dword);
+//   * no E-epilogue reduction, no LDS: dW_p += E (*) t[b,t,:] per group, slabs as in bwd_e_kernel.
+template <bool EXACT, int MMA>
+__global__ __launch_bounds__(256, 2) void bwd_dw_r32_kernel(const BwdEParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int KT = 4, DT = 4;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int D = p.D, R = p.R;
+    const int nblk = gridDim.x * gridDim.y;
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xq = nblk >> 3, xr_ = nblk & 7, xcd = lin & 7;
+    const int logical = (xcd < xr_ ? xcd * (xq + 1) : xr_ * (xq + 1) + (xcd - xr_) * xq) + (lin >> 3);
+    const int dcol = logical % p.ndcol;
+    const int kw = (logical / p.ndcol) % p.nkw;
+    const int sgrp = logical / (p.ndcol * p.nkw);
+    const int d0 = dcol * 64, k0 = kw * 64;
+    const int split = sgrp * 4 + wave;
+    if (split >= p.nsplit) return;
+    const int g_lo = split * p.gps, g_hi = min(p.G, g_lo + p.gps);
+
+    constexpr unsigned OOB = 0x80000000u;
+    const unsigned vx4 = (EXACT || k0 + 4 * r16 < D) ? (unsigned)((long)q * p.xrs + k0 + 4 * r16) * 4u : OOB;
+    const unsigned vy4 = (EXACT || d0 + 4 * r16 < D) ? (unsigned)((long)q * p.yrs + d0 + 4 * r16) * 4u : OOB;
+    const unsigned xbytes = (unsigned)(((long)(R - 1) * p.xrs + D) * 4);
+    const unsigned ybytes = (unsigned)(((long)(R - 1) * p.yrs + D) * 4);
+    const int xstep = (int)(p.xrs * 16), ystep = (int)(p.yrs * 16);     // 4 rows, bytes
+
+    f32x4 dW[KT][DT];
+#pragma unroll
+    for (int it = 0; it < KT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < DT; ++jt) dW[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // reduction position (lane quarter q, element j) is row 4 j + q of the group, for both operands
+    u32x4 xraw[8];
+    auto load_x = [&](int g) {
+        const int g1 = g / p.G2, g2 = g - g1 * p.G2;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X + (long)g1 * p.xs1 + (long)g2 * p.xs2), 0, xbytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xraw[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, vx4, j * xstep, 0);
+    };
+    bf16x8 ybf[DT], ybl[DT];
+    int y_g1 = -1;
+    if (g_lo < g_hi) load_x(g_lo);
+    for (int g = g_lo; g < g_hi; ++g) {
+        const int g1 = g / p.G2;
+        if (g1 != y_g1) {                                                // a new impression: its history rows, split once
+            y_g1 = g1;
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Y + (long)g1 * p.ys1), 0, ybytes, 0x00020000);
+            f32x4 yraw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) yraw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, vy4, j * ystep, 0));
+#pragma unroll
+            for (int jt = 0; jt < DT; ++jt)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const __bf16 hb = (__bf16)yraw[j][jt];
+                    ybf[jt][j] = hb;
+                    if (MMA == 2) ybl[jt][j] = (__bf16)(yraw[j][jt] - (float)hb);
+                }
+        }
+        // scale row of the group (the candidate's t row), consumed after the MFMAs
+        const float* srow = p.srow + (long)g * p.lds_;
+        const f32x4 sr = *reinterpret_cast<const f32x4*>(srow + ((EXACT || d0 + 4 * r16 < D) ? d0 + 4 * r16 : 0));
+        // X fragments: tile it takes 16-bit half (it & 1) of dword (it >> 1) [hi] / 2 + (it >> 1) [lo] of every row's hl4 unit
+        u32x4 afu[KT], alu[KT];
+#pragma unroll
+        for (int it = 0; it < KT; ++it) {
+            const unsigned sel = (it & 1) ? 0x07060302u : 0x05040100u;
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {
+                afu[it][jp] = __builtin_amdgcn_perm(xraw[2 * jp + 1][it >> 1], xraw[2 * jp][it >> 1], sel);
+                if (MMA == 2) alu[it][jp] = __builtin_amdgcn_perm(xraw[2 * jp + 1][2 + (it >> 1)], xraw[2 * jp][2 + (it >> 1)], sel);
+            }
+        }
+        if (g + 1 < g_hi) load_x(g + 1);                                 // next group's dz rows: under this group's MFMAs
+        f32x4 E[KT][DT];
+#pragma unroll
+        for (int it = 0; it < KT; ++it) {
+            const bf16x8 af = __builtin_bit_cast(bf16x8, afu[it]);
+            const bf16x8 al = __builtin_bit_cast(bf16x8, alu[it]);
+#pragma unroll
+            for (int jt = 0; jt < DT; ++jt) {
+                f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (MMA == 2) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ybf[jt], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ybl[jt], c, 0, 0, 0);
+                }
+                E[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ybf[jt], c, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int jt = 0; jt < DT; ++jt)
+#pragma unroll
+            for (int it = 0; it < KT; ++it) dW[it][jt] += E[it][jt] * sr[jt];
+    }
+
+    // slab layout is TRANSPOSED: ws[split][d][k]; lane holds dW[it][jt][e] = dW_p[k0 + 16 q + 4 e + it][d0 + 4 r16 + jt]
+    float* wsp = p.ws + (long)split * D * D;
+#pragma unroll
+    for (int jt = 0; jt < DT; ++jt) {
+        const int d = d0 + 4 * r16 + jt;
+        if (!(EXACT || d < D)) continue;
+        float* row = wsp + (long)d * D + k0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int kk = 16 * q + 4 * e;
+            if (EXACT || k0 + kk < D)
+                *reinterpret_cast<f32x4*>(row + kk) = f32x4{dW[0][jt][e], dW[1][jt][e], dW[2][jt][e], dW[3][jt][e]};
+        }
+    }
+#endif
+}
+
 // min_gps: lower bound on the groups a split walks.  The dt/dW pass passes 96: every split of it writes a [D, D] partial
 // slab of dW_p (C2-small at the old 40 groups per split: 384 slabs = 100 MB for a 256 KB gradient; 5.73 -> 5.68 ms per step
 // with 120); C3's 126 groups per split are unaffected.
@@ -776,6 +948,28 @@ static hipError_t launch_e_t(BwdEParams p, const BwdEPlan& pl, bool with_dw, int
     if constexpr (KT != 4) {
         if (mma != 0) return hipErrorInvalidValue;      // bwd_e_plan gives the bf16 forms 4x4 tiles only
     } else if (mma == 1 || mma == 2) {
+        if (!p.with_dt || p.x_hl4) {                    // the dW_p-only pass of the resident-W backward (hl4 dz operand)
+            if (!with_dw || p.with_dt || !p.x_hl4) return hipErrorInvalidValue;
+            static const bool r32 = [] { const char* e = getenv("NRM_DW_R32"); return !(e && e[0] == '0'); }();
+            if (r32 && p.R <= 32) {                     // one 32-row MFMA step per group: Y kept in registers, X prefetched
+                if (mma == 1) {
+                    if (exact) hipLaunchKernelGGL((bwd_dw_r32_kernel<true, 1>), grid, block, 0, st, p);
+                    else       hipLaunchKernelGGL((bwd_dw_r32_kernel<false, 1>), grid, block, 0, st, p);
+                } else {
+                    if (exact) hipLaunchKernelGGL((bwd_dw_r32_kernel<true, 2>), grid, block, 0, st, p);
+                    else       hipLaunchKernelGGL((bwd_dw_r32_kernel<false, 2>), grid, block, 0, st, p);
+                }
+                return hipGetLastError();
+            }
+            if (mma == 1) {
+                if (exact) hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, true, 1, false, true>), grid, block, 0, st, p);
+                else       hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, false, 1, false, true>), grid, block, 0, st, p);
+            } else {
+                if (exact) hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, true, 2, false, true>), grid, block, 0, st, p);
+                else       hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, false, 2, false, true>), grid, block, 0, st, p);
+            }
+            return hipGetLastError();
+        }
 #define NRM_LAUNCH_E(M)                                                                                              \
         if (with_dw) {                                                                                               \
             if (exact) hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, true, M>), grid, block, 0, st, p);       \
@@ -799,6 +993,11 @@ static hipError_t launch_e_t(BwdEParams p, const BwdEPlan& pl, bool with_dw, int
         else       hipLaunchKernelGGL((bwd_e_kernel<KT, DT, DT, false, false>), grid, block, 0, st, p);
     }
     return hipGetLastError();
+}
+
+int pwattn_bwd_diag_flags() {
+    return (NRM_EPI_AHEAD != 1 ? 8 : 0) | (NRM_DIAG_GELU_AT_LOAD ? 16 : 0) | (NRM_DIAG_NOEPI ? 32 : 0) | (NRM_DIAG_NOATOM ? 64 : 0) |
+           (NRM_DIAG_NOLOAD ? 128 : 0) | (NRM_PIPE_SGB != 1 ? 256 : 0);
 }
 
 hipError_t bwd_e_launch(const BwdEParams& p, const BwdEPlan& pl, bool with_dw, int mma, hipStream_t st) {

@@ -295,6 +295,8 @@ bool pwattn_fwd_uses_rw(int D, int mma) {
     return mode == 2 || (mode == 1 && pl.nsplit == 1);
 }
 
+int pwattn_fwd_diag_flags() { return (NRM_DIAG_FWD ? 1 : 0) | (XCD_REMAP != 1 ? 2 : 0); }
+
 hipError_t pack_wp_launch(const float* w, int ldw, int D, const FwdPlan& pl, int mma, float* packed, hipStream_t st) {
     if (mma) return pack_wp_bf16_launch(w, ldw, D, mma, packed, st);
     const int rows = pwattn_fwd_uses_rw(D, 0) ? pwattn_rw_plan(D, 0).rows : pl.rows;       // same image, the kernel's row padding

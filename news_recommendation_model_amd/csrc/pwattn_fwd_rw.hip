@@ -130,6 +130,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, FB_WAVES / 4) void pwattn_fwd_rw_ker
     const float b2 = split == 0 ? p.b2[0] : 0.f;
     const int ntile = (M + 15) >> 4;
     const int stride = wgs_per_split * FB_WAVES;
+    const bool ragged = D % (CB / 4) != 0;
 
     for (int tile = g * FB_WAVES + wave; tile < ntile; tile += stride) {
         const int m = tile * 16 + r16;
@@ -144,11 +145,19 @@ __global__ __launch_bounds__(FB_WAVES * 64, FB_WAVES / 4) void pwattn_fwd_rw_ker
         f32x4 ta[2], tb[2], ha[2], hb[2];                              // two chunk sets of this lane's operand columns
         auto load_th = [&](int c, int set) {
             if ((NRM_DIAG_RW & 4) && c > 1) return;
-            ta[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_t, voff_t, c * CB, 0));
-            ha[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, voff_h, c * CB, 0));
+            // ragged last chunk (D not a multiple of the chunk width): columns >= D belong to the NEXT row -- they would be
+            // multiplied by the zero padding of W_p, but a NaN / Inf there must not reach this row's scores: read 0 instead
+            unsigned vt = voff_t, vh = voff_h, vt2 = voff_t, vh2 = voff_h;
+            if (ragged) {
+                const int col = (CB / 4) * c + 4 * q;
+                if (col >= D) vt = vh = OOB;
+                if (col + 16 >= D) vt2 = vh2 = OOB;
+            }
+            ta[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_t, vt, c * CB, 0));
+            ha[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, vh, c * CB, 0));
             if (MMA) {
-                tb[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_t, voff_t, c * CB + 64, 0));
-                hb[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, voff_h, c * CB + 64, 0));
+                tb[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_t, vt2, c * CB + 64, 0));
+                hb[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, vh2, c * CB + 64, 0));
             }
         };
         load_th(0, 0);
@@ -237,13 +246,10 @@ __global__ __launch_bounds__(FB_WAVES * 64, FB_WAVES / 4) void pwattn_fwd_rw_ker
 #endif
 }
 
-static int rw_cus() {
-    static const int n = [] {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-        return cus > 0 ? cus : 256;
-    }();
-    return n;
+static int rw_cus() {       // of the CURRENT device (a process may drive several): queried per launch, not cached
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    return cus > 0 ? cus : 256;
 }
 
 template <int NTS>
@@ -262,12 +268,9 @@ static hipError_t launch_rw(const FwdParams& p, const RwPlan& pl, int mma, hipSt
 #define NRM_RW(SZ, M_)                                                                                                   \
     {                                                                                                                    \
         auto k = pwattn_fwd_rw_kernel<NTS, SZ, M_>;                                                                      \
-        static bool attr_set = false;                        /* once per instantiation (idempotent if raced) */        \
-        if (!attr_set) {                                                                                                 \
-            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS_BUDGET);  \
-            if (e != hipSuccess) return e;                                                                               \
-            attr_set = true;                                                                                             \
-        }                                                                                                                \
+        /* per launch: the attribute is per device, and a process may launch on more than one */                        \
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS_BUDGET);  \
+        if (e != hipSuccess) return e;                                                                                   \
         hipLaunchKernelGGL(k, grid, block, shm, st, p, pl, wgs);                                                         \
     }
     if (mma == 2)      { if (p.z) NRM_RW(true, 2) else NRM_RW(false, 2) }
@@ -276,6 +279,8 @@ static hipError_t launch_rw(const FwdParams& p, const RwPlan& pl, int mma, hipSt
 #undef NRM_RW
     return hipGetLastError();
 }
+
+int pwattn_fwd_rw_diag_flags() { return NRM_DIAG_RW ? 4 : 0; }
 
 hipError_t pwattn_fwd_rw_launch(const FwdParams& p, int mma, hipStream_t st) {
     const RwPlan pl = pwattn_rw_plan(p.D, mma);

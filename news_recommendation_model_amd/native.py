@@ -11,7 +11,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NRM_HOTPATH_LIB") or os.path.join(_HERE, "libnrm_hotpath.so")   # override: diagnostic builds (scripts/_diag)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c_fp = ctypes.c_void_p      # device pointers travel as integers
 _c_i, _c_l = ctypes.c_int, ctypes.c_long
@@ -20,12 +20,17 @@ _c_i, _c_l = ctypes.c_int, ctypes.c_long
 SIGNATURES = {
     "nrm_abi_version": (_c_i, []),
     "nrm_last_error": (ctypes.c_char_p, []),
+    "nrm_build_flags": (_c_i, []),
     "nrm_pwattn_packed_floats": (_c_l, [_c_i]),
     "nrm_pwattn_pack_wp": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp]),
     "nrm_pwattn_fwd": (_c_i, [_c_fp] * 9 + [_c_i] * 5 + [_c_fp]),
-    "nrm_pwattn_bwd_dz": (_c_i, [_c_fp] * 6 + [_c_i] * 4 + [_c_fp]),
+    "nrm_pwattn_bwd_dz": (_c_i, [_c_fp] * 6 + [_c_i] * 5 + [_c_fp]),
+    "nrm_pwattn_bwd_rw_supported": (_c_i, [_c_i, _c_i]),
+    "nrm_pwattn_bwd_rw_packed_floats": (_c_l, [_c_i, _c_i]),
+    "nrm_pwattn_bwd_rw_pack": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp]),
+    "nrm_pwattn_bwd_rw_dtdh": (_c_i, [_c_fp] * 6 + [_c_i] * 5 + [_c_fp]),
     "nrm_pwattn_bwd_nsplit": (_c_i, [_c_i] * 5),
-    "nrm_pwattn_bwd_contract": (_c_i, [_c_fp] * 4 + [_c_i] + [_c_fp] * 3 + [_c_i] * 6 + [_c_fp]),
+    "nrm_pwattn_bwd_contract": (_c_i, [_c_fp] * 4 + [_c_i] + [_c_fp] * 3 + [_c_i] * 7 + [_c_fp]),
     "nrm_gemm_packed_floats": (_c_l, [_c_i, _c_i]),
     "nrm_gemm_pack": (_c_i, [_c_fp, _c_l, _c_l, _c_i, _c_i, _c_fp, _c_fp]),
     "nrm_gemm_nt": (_c_i, [_c_fp, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_fp, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_i, _c_fp]),
@@ -94,6 +99,11 @@ def load():
             fn.restype, fn.argtypes = res, args
         if lib.nrm_abi_version() != ABI_VERSION:
             raise RuntimeError(f"ABI mismatch: library {lib.nrm_abi_version()} != binding {ABI_VERSION}; rebuild")
+        flags = lib.nrm_build_flags()
+        if flags and os.environ.get("NRM_ALLOW_DIAG_LIB") != "1":
+            raise RuntimeError(
+                f"{LIB_PATH} is a timing-diagnostic build (nrm_build_flags() = {flags:#x}: kernels with parts of their work "
+                "removed, results are wrong by construction); set NRM_ALLOW_DIAG_LIB=1 to load it for timing experiments")
         _lib = lib
     return _lib
 

@@ -18,6 +18,7 @@ from . import native
 
 EPI_BIAS, EPI_GELU, EPI_DGELU, EPI_MUL = 0, 1, 2, 3
 MMA_F32, MMA_BF16, MMA_BF16X3 = 0, 1, 2     # NRM_MMA_* of include/nrm_hotpath.h: arithmetic of the attention's bilinear contraction
+DZ_F32, DZ_HL4 = 0, 1                       # NRM_DZ_*: layout in which the dz pass leaves dz (fp32 | bf16 hi/lo pairs)
 _MMA_NAMES = {"f32": MMA_F32, "fp32": MMA_F32, "float32": MMA_F32, "bf16": MMA_BF16, "bfloat16": MMA_BF16, "bf16x3": MMA_BF16X3}
 _default_mma = MMA_F32
 
@@ -345,11 +346,14 @@ def _pwattn_bwd_impl(ds, t, h, w1, w2, z, mma):
     w2v = _f32c(w2).reshape(-1)
     dev = t.device
     dw2 = torch.zeros(D, dtype=torch.float32, device=dev)
-    # one pass over z: z -> dz in place, du = sum_t dz, dv = sum_h dz, dw2
+    # one pass over z: z -> dz in place, du = sum_t dz, dv = sum_h dz, dw2.  The bf16 arithmetics with a resident-W backward
+    # (D <= 256) get dz as bf16 hi/lo pairs (NRM_DZ_HL4): the contraction kernels then read MFMA-ready operands
+    lib = native.load()
+    rw = mma != MMA_F32 and bool(lib.nrm_pwattn_bwd_rw_supported(D, mma))
     du = torch.empty(B, H, D, dtype=torch.float32, device=dev)
     dv = torch.empty(B, T, D, dtype=torch.float32, device=dev)
     native.call("nrm_pwattn_bwd_dz", native.ptr(z), native.ptr(ds), native.ptr(w2v), native.ptr(dw2),
-                native.ptr(du), native.ptr(dv), B, T, H, D, st)
+                native.ptr(du), native.ptr(dv), B, T, H, D, DZ_HL4 if rw else DZ_F32, st)
     dz = z
     db2 = ds.sum().reshape(1)
     w_h, w_t, w_d = w1[:, :D], w1[:, D:2 * D], w1[:, 2 * D:3 * D]
@@ -365,15 +369,25 @@ def _pwattn_bwd_impl(ds, t, h, w1, w2, z, mma):
     # du (W_h - W_d), dv (W_t + W_d): the transposed orientation of the same two combinations   (D % 4 == 0: contiguous results)
     dh = _gemm_nt(du2, w_h, 1, 4 * D, D, D, None, EPI_BIAS, src2=w_d, sign2=-1.0, owner=own)[0].reshape(B, H, D)
     dt = _gemm_nt(dv2, w_t, 1, 4 * D, D, D, None, EPI_BIAS, src2=w_d, sign2=1.0, owner=own)[0].reshape(B, T, D)
-    nsplit = native.load().nrm_pwattn_bwd_nsplit(B, T, H, D, mma)
+    nsplit = lib.nrm_pwattn_bwd_nsplit(B, T, H, D, mma)
     wsp = torch.empty(nsplit, D, D, dtype=torch.float32, device=dev)
     wp = w1[:, 3 * D:]                                   # view, row stride 4D
-    # two launches: (b,t)-grouped -> dt + dW_p slabs, (b,h)-grouped -> dh (issued separately so that
-    # bench.py can time each kernel with its own event pair)
-    for passes, tag in ((1, "pwattn_bwd_e_bt"), (2, "pwattn_bwd_e_bh")):
-        native.call("nrm_pwattn_bwd_contract", native.ptr(dz), native.ptr(t), native.ptr(h),
-                    native.ptr(wp), 4 * D, native.ptr(dt), native.ptr(dh), native.ptr(wsp), B, T, H, D,
-                    passes, mma, st, tag=tag)
+    if rw:
+        # resident-W form: dt and dh from ONE contraction dP = dz W_p (dz read once), then the (b,t)-grouped pass without its dt
+        # epilogue for the dW_p slabs
+        img = torch.empty(lib.nrm_pwattn_bwd_rw_packed_floats(D, mma), dtype=torch.float32, device=dev)
+        native.call("nrm_pwattn_bwd_rw_pack", native.ptr(w1), 4 * D, D, mma, native.ptr(img), st)
+        native.call("nrm_pwattn_bwd_rw_dtdh", native.ptr(dz), native.ptr(t), native.ptr(h), native.ptr(img), native.ptr(dt),
+                    native.ptr(dh), B, T, H, D, mma, st, tag="pwattn_bwd_rw_dtdh")
+        native.call("nrm_pwattn_bwd_contract", native.ptr(dz), native.ptr(t), native.ptr(h), native.ptr(wp), 4 * D, None, None,
+                    native.ptr(wsp), B, T, H, D, 4, mma, DZ_HL4, st, tag="pwattn_bwd_e_bt")
+    else:
+        # two launches: (b,t)-grouped -> dt + dW_p slabs, (b,h)-grouped -> dh (issued separately so that
+        # bench.py can time each kernel with its own event pair)
+        for passes, tag in ((1, "pwattn_bwd_e_bt"), (2, "pwattn_bwd_e_bh")):
+            native.call("nrm_pwattn_bwd_contract", native.ptr(dz), native.ptr(t), native.ptr(h),
+                        native.ptr(wp), 4 * D, native.ptr(dt), native.ptr(dh), native.ptr(wsp), B, T, H, D,
+                        passes, mma, DZ_F32, st, tag=tag)
     _slab_reduce(wsp, nsplit, D, D, D, dw1[:, 3 * D:], 4 * D, 1)    # slabs hold dW_p^T: ws[s][d][k] -> dw1[k, 3D + d]
     return dt, dh, dw1, db1, dw2, db2
 

@@ -31,13 +31,27 @@ def test_abi_version_and_sizes(lib):
     assert lib.nrm_pwattn_bwd_nsplit(1, 1, 1, 64, 0) == 1
 
 
+def test_in_tree_library_is_a_product_build(lib):
+    """nrm_build_flags() is the OR of every timing-diagnostic override (scripts/_diag): 0 for the library the tests run."""
+    assert lib.nrm_build_flags() == 0
+
+
+def test_resident_w_backward_plan(lib):
+    # bf16 arithmetics with D <= 256 have the resident-W backward; fp32 and wider attentions keep the E-form
+    assert lib.nrm_pwattn_bwd_rw_supported(256, 2) == 1 and lib.nrm_pwattn_bwd_rw_supported(64, 1) == 1
+    assert lib.nrm_pwattn_bwd_rw_supported(256, 0) == 0 and lib.nrm_pwattn_bwd_rw_supported(400, 2) == 0
+    assert lib.nrm_pwattn_bwd_rw_packed_floats(256, 2) >= 256 * 256          # hi + lo bf16 images = 4 bytes per weight
+    rc = lib.nrm_pwattn_bwd_contract(None, None, None, None, 256, None, None, None, 2, 3, 4, 64, 4, 2, 0, None)
+    assert rc != 0                                                            # the dW_p-only pass reads NRM_DZ_HL4 only
+
+
 def test_host_validation_rejects_bad_shapes(lib):
     # null pointers / bad D are refused on the host before any launch
     rc = lib.nrm_pwattn_fwd(None, None, None, None, None, None, None, None, None, 2, 3, 4, 66, 0, None)
     assert rc != 0 and b"multiple of 4" in lib.nrm_last_error()
     rc = lib.nrm_pwattn_fwd(None, None, None, None, None, None, None, None, None, 2, 3, 4, 64, 0, None)
     assert rc != 0 and b"null" in lib.nrm_last_error()
-    rc = lib.nrm_pwattn_bwd_contract(None, None, None, None, 256, None, None, None, 1 << 20, 64, 64, 64, 3, 0, None)
+    rc = lib.nrm_pwattn_bwd_contract(None, None, None, None, 256, None, None, None, 1 << 20, 64, 64, 64, 3, 0, 0, None)
     assert rc != 0 and b"2^31" in lib.nrm_last_error()
     rc = lib.nrm_pwattn_fwd(None, None, None, None, None, None, None, None, None, 2, 3, 4, 64, 7, None)
     assert rc != 0 and b"mma" in lib.nrm_last_error()          # unknown arithmetic selector
