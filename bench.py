@@ -63,12 +63,18 @@ def parse():
                          "region), hipGraph replay when it is shorter (the step is then bound by host launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
-                    help="do not bracket every launch with HIP events inside the timed region (the per-kernel durations "
-                         "and the roofline then come from 3 extra eager steps outside it, as with --graph)")
+                    help="(default since round 3) no HIP event pairs inside the timed region: the per-kernel durations and the "
+                         "roofline come from 3 extra eager ONE-STREAM steps outside it, as with --graph")
+    ap.add_argument("--timed-kernel-events", action="store_true",
+                    help="eager mode only: bracket the heavy attention kernels with HIP events INSIDE the timed region (the "
+                         "round-1/2 behaviour); the step then runs on one stream, i.e. without the weight-gradient stream")
     ap.add_argument("--pcie", action="store_true",
                     help="also time the steps with the float64 host batch copied to HBM every step (as the reference's "
                          "DataLoader + .to(device) does), prefetched one batch ahead on a copy stream; reported as "
                          "'pcie_inclusive', never as 'value'")
+    ap.add_argument("--timeout", type=float, default=900.0,
+                    help="--gpus N > 1 without a launcher: seconds after which rank processes that are still running are "
+                         "terminated (then killed) and the parent exits with code 124, naming the ranks that hung")
     ap.add_argument("--cpu-batch", type=int, default=None)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -176,10 +182,22 @@ def fwd_auc_parity(dev, mma="f32", case_name="c3_large"):
         sys.path.pop(0)
 
 
+def collective_stats(opt, world):
+    """Mean duration of the step's one all-reduce over the timed steps (event pair on the launch stream around it: the wait of
+    the compute stream for the collective is inside) and its bus bandwidth 2 (N-1)/N * bytes / t -- what a scaling run needs to
+    tell whether xGMI is the limiter."""
+    ev = getattr(opt, "collective_events", None)
+    if not ev:
+        return {"allreduce_ms": None, "bus_GBps": None}
+    ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    bus = (2.0 * (world - 1) / world * opt.nbytes / (ms * 1e-3) / 1e9) if world > 1 and ms > 0 else 0.0
+    return {"allreduce_ms": round(ms, 4), "bus_GBps": round(bus, 2), "allreduce_events": len(ev)}
+
+
 HEAVY = ("nrm_pwattn_fwd", "pwattn_bwd_e_bt", "pwattn_bwd_e_bh", "pwattn_bwd_rw_dtdh", "nrm_pwattn_bwd_dz")   # event-timed inside the timed region
 
 
-def self_launch(n):
+def self_launch(n, timeout=900.0):
     """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes of this one (the same
     command line, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their environment) and leave with the worst exit code.
     Nothing in this process has touched the GPU yet (device_count() does not initialise it), and nothing is
@@ -202,19 +220,45 @@ def self_launch(n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    worst, alive = 0, list(procs)
+    raise SystemExit(wait_for_ranks(procs, timeout))
+
+
+def wait_for_ranks(procs, timeout, grace=10.0, out=sys.stderr):
+    """Wait for the rank processes.  One rank failing -> its peers (which would wait in a collective forever) are terminated
+    and the first failure's code is returned.  ``timeout`` seconds without all of them exiting -> every survivor is terminated,
+    after ``grace`` more seconds killed, the ranks that were still alive are named on ``out`` and 124 is returned.  Nothing is
+    ever re-exec'ed."""
+    t0 = time.monotonic()
+    worst, alive = 0, {r: pr for r, pr in enumerate(procs)}
     while alive:
-        for pr in list(alive):
+        for r, pr in list(alive.items()):
             rc = pr.poll()
             if rc is None:
                 continue
-            alive.remove(pr)
-            if rc != 0:
-                worst = worst or rc
-                for other in alive:                 # one rank died: its peers would wait in a collective forever
+            del alive[r]
+            if rc != 0 and not worst:
+                worst = rc
+                print(f"bench.py: rank {r} exited with code {rc}; stopping ranks {sorted(alive)}", file=out, flush=True)
+                for other in alive.values():            # one rank died: its peers would wait in a collective forever
                     other.terminate()
+        if alive and time.monotonic() - t0 > timeout:
+            hung = sorted(alive)
+            print(f"bench.py: ranks {hung} still running after {timeout:.0f} s (a collective that never completed?): "
+                  "terminating them", file=out, flush=True)
+            for pr in alive.values():
+                pr.terminate()
+            t1 = time.monotonic()
+            while any(pr.poll() is None for pr in alive.values()) and time.monotonic() - t1 < grace:
+                time.sleep(0.1)
+            for r, pr in alive.items():
+                if pr.poll() is None:
+                    print(f"bench.py: rank {r} ignored SIGTERM, killing it", file=out, flush=True)
+                    pr.kill()
+            for pr in alive.values():
+                pr.wait()
+            return 124
         time.sleep(0.2)
-    raise SystemExit(worst)
+    return worst
 
 
 def main():
@@ -222,7 +266,7 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        self_launch(args.gpus)
+        self_launch(args.gpus, args.timeout)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -247,6 +291,20 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+
+    devices = None
+    if use_dist:
+        # every rank on its own physical device (unless this is the one-GPU rehearsal): gathered and checked by every rank
+        pr_ = torch.cuda.get_device_properties(local)
+        ident = {"rank": rank, "current_device": torch.cuda.current_device(), "name": pr_.name,
+                 "uuid": str(getattr(pr_, "uuid", "")), "pci": f"{getattr(pr_, 'pci_domain_id', 0):04x}:{getattr(pr_, 'pci_bus_id', -1):02x}:"
+                                                              f"{getattr(pr_, 'pci_device_id', -1):02x}"}
+        devices = [None] * world
+        dist.all_gather_object(devices, ident)
+        distinct = len({(d["uuid"], d["pci"]) for d in devices}) == world
+        if not distinct and os.environ.get("NRM_SINGLE_DEVICE") != "1":
+            raise SystemExit(f"bench.py: {world} ranks but their devices are not distinct: {devices} "
+                             "(one process per GPU; NRM_SINGLE_DEVICE=1 only for the one-GPU rehearsal)")
 
     from news_recommendation_model_amd import native, synth, trainer
     from news_recommendation_model_amd.config import Dims, WORKLOADS
@@ -288,9 +346,17 @@ def main():
     # shares the chip with a kernel of the other branch cannot be priced against a roofline, so every event-timed step runs
     # on ONE stream; the timed region uses both only where no kernel events are taken inside it (graph replay).
     inv = model.invariant_interest_model
+    if not args.timed_kernel_events:
+        args.no_kernel_timing = True
+    else:
+        os.environ["NRM_WGRAD_STREAM"] = "0"           # event-timed kernels must own the machine
     if args.graph or args.no_kernel_timing:
-        # per-kernel durations cannot be event-timed inside a graph: take them from 3 eager steps first
+        # per-kernel durations cannot be event-timed inside a graph, and a kernel that shares the chip with a kernel of another
+        # stream cannot be priced against a roofline: take them from 3 eager ONE-STREAM steps first (no second attention stream,
+        # no weight-gradient stream)
         inv.two_streams = False
+        prev_wg = os.environ.get("NRM_WGRAD_STREAM")
+        os.environ["NRM_WGRAD_STREAM"] = "0"
         for _ in range(2):
             trainer.train_step(model, opt, tb, reducer)
         sync()
@@ -300,6 +366,10 @@ def main():
         sync()
         events, native.kernel_events = native.kernel_events, None
         inv.two_streams = None
+        if prev_wg is None:
+            del os.environ["NRM_WGRAD_STREAM"]
+        else:
+            os.environ["NRM_WGRAD_STREAM"] = prev_wg
         if args.graph:
             step = trainer.GraphedTrainStep(model, opt, tb)
             run = step.replay
@@ -308,6 +378,8 @@ def main():
         for _ in range(args.warmup):
             run()
         sync()
+        if use_dist and not args.graph:
+            opt.collective_events = []                 # an event pair around the step's one all-reduce
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss, _ = run()
@@ -327,6 +399,8 @@ def main():
         table_events = native.kernel_events
         native.kernel_event_tags = set(HEAVY)
         native.kernel_events = []
+        if use_dist:
+            opt.collective_events = []
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss, _ = trainer.train_step(model, opt, tb, reducer)
@@ -434,14 +508,18 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: EBNeRD-large-shape synthetic" if args.workload == "C3-large" else args.workload,
                        "per_gpu_batch": B, "global_batch": world * B, "hist": H, "candidates": T, "emb": D,
-                       "user_num": user_num, "parallelism": f"dp{world}", "attention_streams": 2 if inv.uses_two_streams(B * T * H * D) else 1, "launch": "hipGraph replay" if args.graph else "eager, untimed kernels" if args.no_kernel_timing else "eager",
+                       "user_num": user_num, "parallelism": f"dp{world}", "attention_streams": 2 if (inv.uses_two_streams(B * T * H * D) and not args.timed_kernel_events) else 1,
+                       "weight_gradient_stream": bool(_ops._wgrad["streams"]) and not args.timed_kernel_events,
+                       "kernel_durations_from": "timed region (event pairs on the launch stream)" if args.timed_kernel_events else "3 extra eager one-stream steps after the warm-up", "launch": "hipGraph replay" if args.graph else "eager",
                        "step": "fwd+loss+bwd+allreduce+Adam(wd=1e-5)" if use_dist else "fwd+loss+bwd+Adam(wd=1e-5)"},
             "loss": round(float(loss), 6),
             "roofline": dict(roof, traffic=traffic, traffic_source=traffic_note),
             "kernels": {k: {"launches": v["launches"], "mean_ms": round(v["mean_ms"], 4)} for k, v in kern.items()},
             "grad_allreduce_bytes": opt.nbytes if use_dist else 0, "replicas_in_sync": replicas_in_sync,
-            "collective": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                            "all_reduce_per_step": 1, "launcher": "self (child processes)" if os.environ.get("NRM_BENCH_CHILD") else "external"}
+            "collective": (dict({"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                 "all_reduce_per_step": 1, "launcher": "self (child processes)" if os.environ.get("NRM_BENCH_CHILD") else "external",
+                                 "devices": devices, "devices_distinct": len({(d["uuid"], d["pci"]) for d in devices}) == world},
+                                **collective_stats(opt, world))
                            if use_dist else None),
         }
         if pcie is not None:

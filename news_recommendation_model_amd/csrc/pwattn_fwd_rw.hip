@@ -142,7 +142,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, FB_WAVES / 4) void pwattn_fwd_rw_ker
         const unsigned voff_u = m < M ? (hr * p.ldu + 4 * q) * 4u : OOB;
         const unsigned voff_v = m < M ? (bt * p.ldv + 4 * q) * 4u : OOB;
 
-        f32x4 ta[2], tb[2], ha[2], hb[2];                              // two chunk sets of this lane's operand columns
+        f32x4 ta[3], tb[3], ha[3], hb[3];                              // three chunk sets of this lane's operand columns (requested two chunks ahead)
         auto load_th = [&](int c, int set) {
             if ((NRM_DIAG_RW & 4) && c > 1) return;
             // ragged last chunk (D not a multiple of the chunk width): columns >= D belong to the NEXT row -- they would be
@@ -212,12 +212,16 @@ __global__ __launch_bounds__(FB_WAVES * 64, FB_WAVES / 4) void pwattn_fwd_rw_ker
                 acc[it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[it], pf, acc[it], 0, 0, 0);
             }
         };
-        for (int c = 0; c < K; c += 2) {
-            if (c + 1 < K) load_th(c + 1, 1);
+        if (1 < K) load_th(1, 1);
+        for (int c = 0; c < K; c += 3) {                                // unrolled by the ring length: set indices are constants
+            if (c + 2 < K) load_th(c + 2, 2);
             compute(c, 0);
             if (c + 1 >= K) break;
-            if (c + 2 < K) load_th(c + 2, 0);
+            if (c + 3 < K) load_th(c + 3, 0);
             compute(c + 1, 1);
+            if (c + 2 >= K) break;
+            if (c + 4 < K) load_th(c + 4, 1);
+            compute(c + 2, 2);
         }
 
         // ---- epilogue: optional z store ; GELU ; partial fc2 dot over the slice's columns

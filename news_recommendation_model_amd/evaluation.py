@@ -66,7 +66,8 @@ def validate(models, batches):
         auc_sum += auc.double().sum()
         hit_sum += top1.double().sum()
         n += scores.shape[0]
-    ops.check_index_errors("cuda")               # an out-of-range table index in any batch (the reference raises IndexError)
+    # an out-of-range table index in any batch (the reference raises IndexError); the flag of the MODELS' device
+    ops.check_index_errors(next(models[0].parameters()).device)
     return [float(auc_sum / n), float(hit_sum / n)]
 
 

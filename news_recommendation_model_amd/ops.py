@@ -119,6 +119,14 @@ def _pack_desc(src, rs, cs, nrows, ncols, src2, sign2, buf):
                            int(nrows), int(ncols), buf.data_ptr())
 
 
+def _pack_desc_of(ent, owner):
+    """Descriptor of a cached entry, addresses taken from its live owner (byte offsets were stored, not views)."""
+    off, rs, cs, nrows, ncols, off2, sign2 = ent.spec
+    base = owner.data_ptr()
+    return native.PackDesc(base + off, (base + off2) if off2 is not None else None, float(sign2), int(rs), int(cs),
+                           int(nrows), int(ncols), ent.buf.data_ptr())
+
+
 def _pack(src, rs, cs, nrows, ncols, src2=None, sign2=0.0, owner=None):
     """Packed image of the logical [nrows x ncols] matrix src[r*rs + c*cs] (+ sign2 * src2[same]); see _PackedWeights."""
     import weakref
@@ -138,8 +146,11 @@ def _pack(src, rs, cs, nrows, ncols, src2=None, sign2=0.0, owner=None):
         ent = _PackEntry()
         ent.buf = torch.empty(lib.nrm_gemm_packed_floats(nrows, ncols), dtype=torch.float32, device=src.device)
         ent.owner, ent.owner_ptr = weakref.ref(owner), owner.data_ptr()
-        ent.spec = (src, rs, cs, nrows, ncols, src2, sign2)          # views keep the parameter's storage alive
+        # the views are rebuilt from the live owner when needed (a stored view would keep a dead model's storage alive)
+        ent.spec = (src.data_ptr() - owner.data_ptr(), rs, cs, nrows, ncols,
+                    (src2.data_ptr() - owner.data_ptr()) if src2 is not None else None, sign2)
         _packs.entries[key] = ent
+        weakref.finalize(owner, _packs.entries.pop, key, None)     # the entry goes when its parameter goes
     d = _pack_desc(src, rs, cs, nrows, ncols, src2, sign2, ent.buf)
     native.call("nrm_gemm_pack_multi", _ctypes_ref(d), 1, native.stream_ptr())
     ent.version, ent.epoch = owner._version, _packs.epoch
@@ -151,21 +162,26 @@ def _ctypes_ref(desc_or_array):
     return ctypes.cast(ctypes.pointer(desc_or_array), ctypes.c_void_p)
 
 
-def repack_persistent(device=None):
-    """Every cached weight image refreshed from its (just updated) parameter by ONE launch; entries whose parameter is gone or
-    has been re-seated are dropped.  Called by trainer.FlatAdam.step(); harmless to call at any time."""
+def repack_persistent(owners=None):
+    """The cached weight images of ``owners`` (an iterable of parameters; None = every live entry) refreshed from their (just
+    updated) parameters by ONE launch; entries whose parameter is gone or has been re-seated are dropped.  Called by
+    trainer.FlatAdam.step() with ITS parameters: a captured step (trainer.GraphedTrainStep) then only bakes in the addresses of
+    the model it was captured for, never those of another live model's entries.  Every other entry is invalidated (``epoch``)
+    and re-packed lazily on its next use."""
     _packs.epoch += 1
+    mine = None if owners is None else {id(o) for o in owners}
     live = []
     for key, ent in list(_packs.entries.items()):
         owner = ent.owner()
-        if owner is None or owner.data_ptr() != ent.owner_ptr or (device is not None and ent.buf.device != torch.device(device)):
-            if owner is None or owner.data_ptr() != ent.owner_ptr:
-                del _packs.entries[key]
+        if owner is None or owner.data_ptr() != ent.owner_ptr:
+            _packs.entries.pop(key, None)
+            continue
+        if mine is not None and id(owner) not in mine:
             continue
         live.append((ent, owner))
     if not live:
         return 0
-    arr = (native.PackDesc * len(live))(*[_pack_desc(*ent.spec, ent.buf) for ent, _ in live])
+    arr = (native.PackDesc * len(live))(*[_pack_desc_of(ent, owner) for ent, owner in live])
     native.call("nrm_gemm_pack_multi", _ctypes_ref(arr), len(live), native.stream_ptr())
     for ent, owner in live:
         ent.version, ent.epoch = owner._version, _packs.epoch
@@ -237,9 +253,35 @@ class deferred_slab_reductions:
         return False
 
 
+def verify_deferred_targets(params):
+    """Every recorded reduction must still point INTO the gradient tensor autograd left on a parameter.  AccumulateGrad adopts
+    the buffer an op returned only while it is the sole owner and the parameter had no gradient; a weight used twice in the
+    graph (autograd sums two not-yet-reduced buffers into a new tensor), a pre-existing ``p.grad`` (accumulated into early), a
+    gradient hook or ``create_graph`` all leave ``p.grad`` in OTHER memory, which the deferred launch would never reach --
+    silently wrong gradients.  Raises instead (and drops the records); such callers must run backward() outside
+    ``deferred_slab_reductions()`` (``trainer.train_step(..., defer_reductions=False)``)."""
+    pend = _deferred["pending"]
+    if not pend:
+        return
+    by_ptr = {p.data_ptr(): p for p in params}
+    for rec in pend:
+        p = by_ptr.get(rec["target"])
+        if p is None or not p.requires_grad:            # a frozen weight (its gradient was dropped by autograd) or an unknown one
+            continue
+        if p.grad is None or p.grad.untyped_storage().data_ptr() != rec["keep"][0].data_ptr():
+            _deferred["pending"] = []
+            _join_wgrad_stream()
+            raise RuntimeError(
+                "deferred slab reductions: a weight gradient was copied or accumulated before its reduction ran (a weight "
+                "used more than once in the graph, a gradient that existed before backward(), a gradient hook, or "
+                "create_graph): its values would be wrong. Run this backward outside ops.deferred_slab_reductions() -- "
+                "trainer.train_step(..., defer_reductions=False).")
+
+
 def flush_slab_reductions():
     """Run every recorded slab reduction (one launch on the current stream); no-op when nothing is pending."""
     pend, _deferred["pending"] = _deferred["pending"], []
+    _join_wgrad_stream()                               # slabs written on the weight-gradient stream
     if not pend:
         return
     descs = (native.SlabDesc * len(pend))()
@@ -253,8 +295,9 @@ def flush_slab_reductions():
 
 
 def _slab_reduce(ws, nsplit, nj, ldws, ni, out, out_is, out_js, out2=None, out2_is=0, out2_js=0, sign2=0.0,
-                 vec=None, vec_out=None):
-    """out (+)= sum over the split slabs (float atomics: ``out`` / ``out2`` must be zero-initialised)."""
+                 vec=None, vec_out=None, target=None):
+    """out (+)= sum over the split slabs (float atomics: ``out`` / ``out2`` must be zero-initialised).  ``target``: the weight
+    whose gradient ``out`` is (verify_deferred_targets checks that autograd really left ``out`` on it)."""
     if _deferred["on"]:
         # (slabs recorded on the second attention's stream need no allocator bookkeeping: that stream waits for the main
         # one before it is given new work, i.e. after the flush that read them)
@@ -262,6 +305,7 @@ def _slab_reduce(ws, nsplit, nj, ldws, ni, out, out_is, out_js, out2=None, out2_
             ws=ws, nsplit=nsplit, nj=nj, ldws=ldws, ni=ni, out=out.data_ptr(), out_is=out_is, out_js=out_js,
             out2=out2.data_ptr() if out2 is not None else None, out2_is=out2_is, out2_js=out2_js, sign2=float(sign2),
             vec=vec, vec_out=vec_out.data_ptr() if vec_out is not None else None,
+            target=target.data_ptr() if target is not None else None,
             keep=(out.untyped_storage(), out2.untyped_storage() if out2 is not None else None,
                   vec_out.untyped_storage() if vec_out is not None else None)))
         return
@@ -271,14 +315,68 @@ def _slab_reduce(ws, nsplit, nj, ldws, ni, out, out_is, out_js, out2=None, out2_
                 native.stream_ptr())
 
 
-def _gemm_tn(a, b, want_colsum):
+# Weight-gradient stream.  dW = dY^T X feeds nothing but the optimizer, so inside ``deferred_slab_reductions()`` (i.e. under
+# trainer.train_step with FlatAdam, where nobody reads a weight gradient before collect_grads) the weight-gradient GEMMs of
+# big batches are issued on a side stream: they fill the gaps the dependent chain dX -> dX -> ... leaves on the chip
+# (C3: -0.9 ms per step).  flush_slab_reductions() joins the side stream before the reductions read the slabs.
+# NRM_WGRAD_STREAM=0|1 forces it off / on; by default it is on for operands of >= WGRAD_STREAM_MIN_ROWS rows.
+WGRAD_STREAM_MIN_ROWS = 20000
+_wgrad = {"streams": {}, "used": set()}
+
+
+class _wgrad_stream:
+    """with _wgrad_stream(a, b) as on_side: ... -- runs the block on the weight-gradient stream when that applies."""
+
+    def __init__(self, *inputs):
+        import os
+        forced = os.environ.get("NRM_WGRAD_STREAM")
+        self.inputs = inputs
+        self.on = _deferred["on"] and (forced == "1" or (forced is None and inputs[0].shape[0] >= WGRAD_STREAM_MIN_ROWS))
+
+    def __enter__(self):
+        if not self.on:
+            return False
+        dev = self.inputs[0].device
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        side = _wgrad["streams"].get(key)
+        if side is None:
+            side = _wgrad["streams"][key] = torch.cuda.Stream(device=dev)
+        self.main = torch.cuda.current_stream(dev)
+        side.wait_stream(self.main)                      # the operands exist once the main stream gets here
+        for t in self.inputs:
+            t.record_stream(side)                        # allocated on the main stream, read by side-stream kernels
+        _wgrad["used"].add(key)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return True
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def _join_wgrad_stream():
+    """The current stream waits for every weight-gradient stream that was given work since the last join."""
+    for key in list(_wgrad["used"]):
+        torch.cuda.current_stream().wait_stream(_wgrad["streams"][key])
+    _wgrad["used"].clear()
+
+
+def _gemm_tn(a, b, want_colsum, target=None):
     """(sum_r a[r,i] b[r,j]) as a contiguous [ni, nj], and optionally sum_r a[r,i]: the split-M GEMM plus ONE
     reduce+transpose launch that writes the gradient in place (no ATen sum/t/contiguous)."""
     ni, nj = a.shape[1], b.shape[1]
-    c = torch.empty(ni, nj, dtype=torch.float32, device=a.device)      # zeroed by the GEMM launch itself
-    ws, cs, nsplit, ldws = _gemm_tn_slabs(a, b, want_colsum, zero_out=c)
-    colsum = torch.empty(ni, dtype=torch.float32, device=a.device) if want_colsum else None
-    _slab_reduce(ws, nsplit, nj, ldws, ni, c, nj, 1, vec=cs, vec_out=colsum)
+    ctx = _wgrad_stream(a, b)
+    with ctx as side:
+        c = torch.empty(ni, nj, dtype=torch.float32, device=a.device)      # zeroed by the GEMM launch itself
+        ws, cs, nsplit, ldws = _gemm_tn_slabs(a, b, want_colsum, zero_out=c)
+        colsum = torch.empty(ni, dtype=torch.float32, device=a.device) if want_colsum else None
+        _slab_reduce(ws, nsplit, nj, ldws, ni, c, nj, 1, vec=cs, vec_out=colsum, target=target)
+        if side:                                           # read (reduced, gathered) and released on the main stream after the join
+            for t in (c, ws, cs, colsum):
+                if t is not None:
+                    t.record_stream(ctx.main)
     return c, colsum
 
 
@@ -361,11 +459,17 @@ def _pwattn_bwd_impl(ds, t, h, w1, w2, z, mma):
     # fc1 gradient [D, 4D] = [da_h | da_t | da_t - da_h | dW_p]: every block is written in place by a slab reduction
     dw1 = torch.empty(D, 4 * D, dtype=torch.float32, device=dev)                    # zeroed by the first GEMM launch below
     db1 = torch.empty(D, dtype=torch.float32, device=dev)
-    ws, cs, ns, ldws = _gemm_tn_slabs(du2, h.reshape(B * H, D), True, zero_out=dw1)  # du^T h, db1 = column sums of du
-    _slab_reduce(ws, ns, D, ldws, D, dw1, 4 * D, 1, out2=dw1[:, 2 * D:], out2_is=4 * D, out2_js=1, sign2=-1.0,
-                 vec=cs, vec_out=db1)
-    ws, _, ns, ldws = _gemm_tn_slabs(dv2, t.reshape(B * T, D), False)
-    _slab_reduce(ws, ns, D, ldws, D, dw1[:, D:], 4 * D, 1, out2=dw1[:, 2 * D:], out2_is=4 * D, out2_js=1, sign2=1.0)
+    h2, t2 = h.reshape(B * H, D), t.reshape(B * T, D)
+    ctx = _wgrad_stream(du2, h2, dv2, t2, dw1)          # (big batches under train_step: on the weight-gradient stream)
+    with ctx as side:
+        ws, cs, ns, ldws = _gemm_tn_slabs(du2, h2, True, zero_out=dw1)  # du^T h, db1 = column sums of du
+        _slab_reduce(ws, ns, D, ldws, D, dw1, 4 * D, 1, out2=dw1[:, 2 * D:], out2_is=4 * D, out2_js=1, sign2=-1.0,
+                     vec=cs, vec_out=db1, target=w1_arg)
+        ws2, _, ns, ldws = _gemm_tn_slabs(dv2, t2, False)
+        _slab_reduce(ws2, ns, D, ldws, D, dw1[:, D:], 4 * D, 1, out2=dw1[:, 2 * D:], out2_is=4 * D, out2_js=1, sign2=1.0, target=w1_arg)
+        if side:
+            for x in (ws, cs, ws2):
+                x.record_stream(ctx.main)
     # du (W_h - W_d), dv (W_t + W_d): the transposed orientation of the same two combinations   (D % 4 == 0: contiguous results)
     dh = _gemm_nt(du2, w_h, 1, 4 * D, D, D, None, EPI_BIAS, src2=w_d, sign2=-1.0, owner=own)[0].reshape(B, H, D)
     dt = _gemm_nt(dv2, w_t, 1, 4 * D, D, D, None, EPI_BIAS, src2=w_d, sign2=1.0, owner=own)[0].reshape(B, T, D)
@@ -388,7 +492,7 @@ def _pwattn_bwd_impl(ds, t, h, w1, w2, z, mma):
             native.call("nrm_pwattn_bwd_contract", native.ptr(dz), native.ptr(t), native.ptr(h),
                         native.ptr(wp), 4 * D, native.ptr(dt), native.ptr(dh), native.ptr(wsp), B, T, H, D,
                         passes, mma, DZ_F32, st, tag=tag)
-    _slab_reduce(wsp, nsplit, D, D, D, dw1[:, 3 * D:], 4 * D, 1)    # slabs hold dW_p^T: ws[s][d][k] -> dw1[k, 3D + d]
+    _slab_reduce(wsp, nsplit, D, D, D, dw1[:, 3 * D:], 4 * D, 1, target=w1_arg)    # slabs hold dW_p^T: ws[s][d][k] -> dw1[k, 3D + d]
     return dt, dh, dw1, db1, dw2, db2
 
 
@@ -493,7 +597,7 @@ def _linear_bwd_impl(dy, x, weight, z, has_bias, need_dx, need_dw):
     dev = x.device
     dw = db = dx = None
     if need_dw:
-        dw, db = _gemm_tn(dy, x, has_bias)                  # dW[n,k] = sum_m dy[m,n] x[m,k]
+        dw, db = _gemm_tn(dy, x, has_bias, target=weight)   # dW[n,k] = sum_m dy[m,n] x[m,k]
     if need_dx:
         dx, _ = _gemm_nt(dy, w, 1, K, K, N, None, EPI_BIAS, owner=w if w is weight else None)  # dX = dY W : rows of the packed operand = k
     e = lambda: torch.empty((0,), dtype=torch.float32, device=dev)      # noqa: E731
@@ -582,6 +686,7 @@ def _mlp_gelu_bwd_impl(dy, x, w1, w2, hidden, z, pre, mul, has_b1, has_b2, need_
     multiplier (the gate), dY is first split by one fused kernel into d(fc2 output) = dY * mul and d(mul) = dY * fc2 output."""
     _require_gpu(dy, x, w1, w2)
     o1, o2 = w1, w2
+    p1, p2 = w1, w2                                                     # the parameters the weight gradients are for
     x, w1, w2 = _rows(x), _f32c(w1), _f32c(w2)
     o1, o2 = (w1 if w1 is o1 else None), (w2 if w2 is o2 else None)
     N1, K1 = w1.shape
@@ -601,10 +706,10 @@ def _mlp_gelu_bwd_impl(dy, x, w1, w2, hidden, z, pre, mul, has_b1, has_b2, need_
             dy, dmul = dg[:, :N2], dmul_buf[:, :N2]
         else:
             dy, dmul = _rows(dy * m), dy * pre
-    dw2, db2 = _gemm_tn(dy, hidden, has_b2)                          # dW2[n,k] = sum_m dy[m,n] hidden[m,k]
+    dw2, db2 = _gemm_tn(dy, hidden, has_b2, target=p2)               # dW2[n,k] = sum_m dy[m,n] hidden[m,k]
     # d(pre-activation of fc1) = (dY W2) * gelu'(z): epilogue 2 reads z and writes the product
     dz, _ = _gemm_nt(dy, w2, 1, K2, K2, N2, None, EPI_DGELU, z=z, owner=o2)
-    dw1, db1 = _gemm_tn(dz, x, has_b1)
+    dw1, db1 = _gemm_tn(dz, x, has_b1, target=p1)
     e = lambda: torch.empty((0,), dtype=torch.float32, device=dev)      # noqa: E731
     dx = _gemm_nt(dz, w1, 1, K1, K1, N1, None, EPI_BIAS, owner=o1)[0] if need_dx else e()
     return dx, dw1, (db1 if has_b1 else e()), dw2, (db2 if has_b2 else e()), dmul

@@ -87,6 +87,7 @@ class FlatAdam:
         # {step, 1-b1^step, sqrt(1-b2^step), -} lives on the device: the step is graph-capturable
         self.state = torch.zeros(4, dtype=torch.float32, device=dev)
         self.param_groups = [{"lr": lr}]                       # what train.py:57 reads
+        self.collective_events = None                          # a list: all_reduce_grads appends an event pair per call (bench.py)
 
     @property
     def nbytes(self):
@@ -107,6 +108,7 @@ class FlatAdam:
         if self._collected:
             return
         from . import native, ops
+        ops.verify_deferred_targets(self.params)   # a deferred reduction whose buffer autograd copied away would be lost: raise
         ops.flush_slab_reductions()                # weight gradients whose slab reduction train_step deferred become valid here
         keep = []
         for i, p in enumerate(self.params):
@@ -132,7 +134,7 @@ class FlatAdam:
                       float(self.weight_decay), bool(zero_grad))          # torch.ops.nrm.adam_step -> nrm_adam_step_dev
         # the weights moved (through a raw pointer: no autograd version bump): every cached packed GEMM operand is
         # refreshed by ONE launch instead of one per GEMM call of the next step
-        ops.repack_persistent()
+        ops.repack_persistent(self.params)
         self._collected = False
 
     def zero_grad(self, set_to_none=False):
@@ -148,12 +150,19 @@ class FlatAdam:
             return
         # issued whenever a process group exists, also for a group of one (bench.py's NRM_DIST_WORLD1 rehearsal of RCCL)
         world = dist.get_world_size(group)
+        timed = self.collective_events is not None and not torch.cuda.is_current_stream_capturing()
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         if dist.get_backend(group) == "nccl":
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.AVG, group=group)      # RCCL averages in the collective
         else:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)
             if world > 1:
                 self.flat_grad.mul_(1.0 / world)
+        if timed:
+            e1.record()
+            self.collective_events.append((e0, e1))
 
 
 class FlatGradReducer:
@@ -192,15 +201,73 @@ class FlatGradReducer:
                 p.grad.copy_(v)
 
 
-def train_step(model, optimizer, batch, reducer: FlatGradReducer | None = None, alpha=0.95):
-    """One step of train.py:69-75 on device-resident tensors; returns (loss, out) detached."""
+class IndexErrorWatch:
+    """Out-of-range ids without a host sync.  The kernels clamp a bad table index / user id and set a device flag (the reference
+    raises IndexError at the offending batch: F.embedding at models/user_invariant_interest_model.py:59, delta[id] at
+    models/user_model.py:40).  ``after_step()`` copies the flag to pinned host memory asynchronously; ``before_step()`` looks at
+    the copies that have landed -- and waits for a copy that is more than ``max_lag`` steps old -- and raises: the error
+    surfaces one step after the offending batch when the device keeps up with the host, ``max_lag`` + 1 steps after it at the
+    latest, instead of at the epoch's end."""
+
+    def __init__(self, device, max_lag=2):
+        from . import ops
+        self.flag = ops.index_error_flag(device)
+        self.device = self.flag.device
+        self.max_lag = max_lag
+        self.pending = []                                   # (pinned host int32[1], event), oldest first
+
+    def after_step(self):
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(self.flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.pending.append((host, ev))
+
+    def before_step(self):
+        while self.pending:
+            host, ev = self.pending[0]
+            if not ev.query():
+                if len(self.pending) <= self.max_lag:
+                    return
+                ev.synchronize()
+            self.pending.pop(0)
+            if int(host[0]):
+                self.pending.clear()
+                self.flag.zero_()
+                raise IndexError("index out of range (a category / type / time table index of a packed feature row, or a user "
+                                 "id outside delta) in a batch of one of the last steps")
+
+
+_watches = {}
+
+
+def _index_watch(device):
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    w = _watches.get(key)
+    if w is None:
+        w = _watches[key] = IndexErrorWatch(device)
+    return w
+
+
+def train_step(model, optimizer, batch, reducer: FlatGradReducer | None = None, alpha=0.95, defer_reductions=True):
+    """One step of train.py:69-75 on device-resident tensors; returns (loss, out) detached.  An out-of-range id of an EARLIER
+    step raises IndexError here, before this step's work is enqueued (IndexErrorWatch)."""
+    watch = _index_watch(batch["x_history"].device) if not torch.cuda.is_current_stream_capturing() else None
+    if watch is not None:
+        watch.before_step()
     out = model(batch["x_history"], batch["x_target"], batch["x_global"])
     loss = model.loss(batch["user_id"], out, batch["label"], alpha)
     if isinstance(optimizer, FlatAdam):
         from . import ops
         # nobody reads a weight gradient between backward() and collect_grads(): the step's slab reductions (one per weight
-        # gradient) are recorded during backward and run as ONE launch when FlatAdam gathers the gradients
-        with ops.deferred_slab_reductions():
+        # gradient) are recorded during backward and run as ONE launch when FlatAdam gathers the gradients.  A gradient that
+        # exists already would be accumulated into before its reduction ran: then (and on request) reductions run at once.
+        defer = defer_reductions and all(p.grad is None for p in optimizer.params)
+        if defer:
+            with ops.deferred_slab_reductions():
+                loss.backward()
+        else:
             loss.backward()
         optimizer.all_reduce_grads()
         optimizer.step(zero_grad=True)                # Adam + zero_grad fused in one launch
@@ -210,6 +277,8 @@ def train_step(model, optimizer, batch, reducer: FlatGradReducer | None = None, 
             reducer.reduce()
         optimizer.step()
         optimizer.zero_grad(set_to_none=False)
+    if watch is not None:
+        watch.after_step()
     return loss.detach(), out.detach()
 
 
@@ -237,7 +306,10 @@ class GraphedTrainStep:
             self.loss, self.out = train_step(model, optimizer, batch, None, alpha)
 
     def replay(self):
+        watch = _index_watch(self.batch["x_history"].device)
+        watch.before_step()                                  # an out-of-range id of an earlier replay raises IndexError here
         self.graph.replay()
+        watch.after_step()
         return self.loss, self.out
 
 
@@ -360,9 +432,10 @@ def train_epochs(model, optimizer, make_loader, epochs, device="cuda", ckpt_path
                 on_batch(epoch, i, loss, auc)
         if int(bad_rows):                                               # checked once per epoch: no per-batch host sync
             raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
-        # an out-of-range table index / user id anywhere in the epoch: the reference raises IndexError at the offending batch
-        # (F.embedding, delta[id]); the kernels clamp, flag and go on, and the flag is read here, at the epoch's one host sync
-        ops.check_index_errors(device)
+        # an out-of-range table index / user id: the reference raises IndexError at the offending batch (F.embedding, delta[id]);
+        # the kernels clamp and flag, train_step raises at the start of the NEXT step (IndexErrorWatch, no host sync); the last
+        # batches of the epoch are covered here, at the epoch's one host sync
+        ops.check_index_errors(next(model.parameters()).device)
         rec = {"epoch": epoch, "lr": lr, "impressions": seen,
                "loss_avg": float(loss_sum / max(seen, 1)), "auc_avg": float(auc_sum / max(seen, 1))}
         history.append(rec)

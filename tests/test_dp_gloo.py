@@ -137,3 +137,35 @@ def test_bench_self_launcher_plumbing_without_gpu():
 def test_bench_rejects_world_size_that_disagrees_with_gpus():
     pr = _bench(["--gpus", "2"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
     assert pr.returncode != 0 and b"must agree" in pr.stderr
+
+
+def test_launcher_deadline_terminates_hung_ranks():
+    """bench.wait_for_ranks: ranks that never exit (a collective that never completes) are terminated -- then killed -- after
+    the deadline, named on stderr, and the launcher returns 124 instead of polling until the driver's kill."""
+    import io
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    try:
+        import bench
+    finally:
+        sys.path.pop(0)
+    sleeper = [sys.executable, "-c", "import time; time.sleep(120)"]
+    stubborn = [sys.executable, "-c", "import signal, time; signal.signal(signal.SIGTERM, signal.SIG_IGN); time.sleep(120)"]
+    quick = [sys.executable, "-c", "pass"]
+    procs = [subprocess.Popen(quick), subprocess.Popen(sleeper), subprocess.Popen(stubborn)]
+    time.sleep(0.5)                                    # let the stubborn rank install its handler
+    log = io.StringIO()
+    t0 = time.monotonic()
+    rc = bench.wait_for_ranks(procs, timeout=1.0, grace=1.0, out=log)
+    assert rc == 124 and time.monotonic() - t0 < 20
+    assert all(pr.poll() is not None for pr in procs)
+    text = log.getvalue()
+    assert "ranks [1, 2] still running" in text and "rank 2 ignored SIGTERM" in text
+    # a failing rank stops its peers and its code comes back
+    procs = [subprocess.Popen([sys.executable, "-c", "import sys; sys.exit(3)"]), subprocess.Popen(sleeper)]
+    log = io.StringIO()
+    assert bench.wait_for_ranks(procs, timeout=30.0, out=log) == 3
+    assert procs[1].poll() is not None and "rank 0 exited with code 3" in log.getvalue()

@@ -75,6 +75,30 @@ def test_bench_self_launches_two_ranks(lib, tmp_path):
     assert line["replicas_in_sync"] is True
     assert line["grad_allreduce_bytes"] > 0
     assert line["collective"]["world_size"] == 2 and line["collective"]["all_reduce_per_step"] == 1
+    # the step's one collective is timed (event pair) and priced as bus bandwidth; every rank's device is
+    # reported, and here -- the one-GPU rehearsal -- they are known NOT to be distinct
+    c = line["collective"]
+    assert c["allreduce_ms"] > 0 and c["allreduce_events"] == 3 and c["bus_GBps"] > 0
+    assert abs(c["bus_GBps"] - 2 * (2 - 1) / 2 * line["grad_allreduce_bytes"] / (c["allreduce_ms"] * 1e-3) / 1e9) < 0.02 * c["bus_GBps"] + 0.01
+    assert len(c["devices"]) == 2 and {d["rank"] for d in c["devices"]} == {0, 1} and c["devices_distinct"] is False
+
+
+def test_bench_refuses_ranks_that_share_a_device(lib, tmp_path):
+    """Two ranks that land on the SAME device without NRM_SINGLE_DEVICE=1 (a launcher that forgot LOCAL_RANK): every rank
+    gathers the device identities and refuses to produce a number."""
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   NRM_DIST_BACKEND="gloo")
+        env.pop("NRM_SINGLE_DEVICE", None)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                                       "--workload", "ref-default", "--batch", "8", "--no-cpu-baseline"],
+                                      env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [pr.communicate(timeout=300)[0].decode(errors="replace") for pr in procs]
+    assert all(pr.returncode != 0 for pr in procs)
+    assert any("not distinct" in o for o in outs), outs[0][-1500:]
 
 
 def test_bench_one_rank_through_rccl(lib, tmp_path):

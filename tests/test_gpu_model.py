@@ -503,3 +503,39 @@ def test_deferred_slab_reductions_with_a_frozen_weight(lib):
     assert abs(float(la) - float(lb)) < 1e-5 * abs(float(lb))
     for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
         assert torch.allclose(pa, pb, rtol=0, atol=2e-5), k
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_weight_gradient_stream_matches_one_stream(lib, monkeypatch, graphed):
+    """ops._wgrad_stream: under trainer.train_step + FlatAdam the weight-gradient GEMMs (dW = dY^T X, and the attention's side
+    projections) may run on a side stream that FlatAdam.collect_grads joins.  Eager and captured into a HIP graph, three
+    optimizer steps with the stream forced on must land where the one-stream steps land (same kernels; only the order of float
+    atomics in the slab reductions can differ), and the stream must really have been used."""
+    from news_recommendation_model_amd import ops, trainer
+    case, one, tb, batch, fx = _model_and_batch("tiny_train")
+    two = _model_and_batch("tiny_train")[1]
+    one.train(); two.train()
+    oopt, topt = trainer.FlatAdam(one), trainer.FlatAdam(two)
+    ops._wgrad["streams"].clear()
+    monkeypatch.setenv("NRM_WGRAD_STREAM", "0")
+    for _ in range(3 + (3 if graphed else 0)):
+        lo, _ = trainer.train_step(one, oopt, tb)
+    assert not ops._wgrad["streams"]
+    monkeypatch.setenv("NRM_WGRAD_STREAM", "1")
+    if graphed:
+        step = trainer.GraphedTrainStep(two, topt, tb, warmup=3)
+        for _ in range(3):
+            lt, _ = step.replay()
+    else:
+        for _ in range(3):
+            lt, _ = trainer.train_step(two, topt, tb)
+    torch.cuda.synchronize()
+    assert ops._wgrad["streams"] and not ops._wgrad["used"]           # used, and joined by collect_grads
+    assert abs(float(lt) - float(lo)) < 1e-4 * abs(float(lo))
+    for (k, a), (_, b) in zip(one.named_parameters(), two.named_parameters()):
+        assert torch.allclose(a, b, rtol=0, atol=5e-4), k
+    # outside train_step (plain backward, torch.optim): gradients are valid as soon as backward() returns -- no side stream
+    ops._wgrad["streams"].clear()
+    out = two(tb["x_history"], tb["x_target"], tb["x_global"])
+    two.loss(tb["user_id"], out, tb["label"]).backward()
+    assert not ops._wgrad["streams"]

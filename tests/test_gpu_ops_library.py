@@ -184,3 +184,59 @@ def test_gate_block_and_concat_match_the_separate_ops(lib):
     g = torch.randn_like(want)
     got.backward(g)
     assert torch.equal(parts[1].grad, g[..., 10:13]) and torch.equal(parts[2].grad, g[..., 13:18])
+
+
+def test_deferred_reductions_refuse_a_weight_used_twice(lib):
+    """inside ops.deferred_slab_reductions() a weight gradient is only valid after the flush.  A weight
+    used twice in the graph makes autograd SUM two not-yet-reduced buffers into a new tensor the flush never reaches:
+    FlatAdam.collect_grads must notice and raise instead of stepping on wrong gradients; with reductions run at once
+    (train_step(..., defer_reductions=False) does this) the same graph gives the right gradient."""
+    import torch
+    from news_recommendation_model_amd import ops, trainer
+
+    class Twice(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc = torch.nn.Linear(8, 8)
+
+        def forward(self, x):
+            return ops.linear(ops.linear(x, self.fc.weight, self.fc.bias), self.fc.weight, self.fc.bias)
+
+    torch.manual_seed(0)
+    mod = Twice().cuda()
+    x = torch.randn(300, 8, device="cuda")
+    opt = trainer.FlatAdam(mod)
+    with ops.deferred_slab_reductions():
+        mod(x).sum().backward()
+    with pytest.raises(RuntimeError, match="deferred slab reductions"):
+        opt.collect_grads()
+    assert not ops._deferred["pending"]
+    for p in mod.parameters():
+        p.grad = None
+    mod(x).sum().backward()                                     # immediate reductions: the reference gradient
+    ref = torch.nn.Linear(8, 8).cuda()
+    ref.load_state_dict({"weight": mod.fc.weight.detach().clone(), "bias": mod.fc.bias.detach().clone()})
+    ref(ref(x)).sum().backward()
+    assert torch.allclose(mod.fc.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-4)
+    # a gradient that exists before backward(): train_step does not defer at all
+    opt.zero_grad()
+
+
+def test_packed_weight_cache_drops_dead_models_and_scopes_the_repack(lib):
+    """entries of the packed-weight cache die with their parameter (no view keeps a dead model's storage
+    alive), and FlatAdam.step() re-packs only its own parameters' images."""
+    import gc
+    import torch
+    from news_recommendation_model_amd import ops, trainer
+    ops.invalidate_packed_weights()
+    a, b = torch.nn.Linear(16, 12).cuda(), torch.nn.Linear(16, 12).cuda()
+    x = torch.randn(70, 16, device="cuda")
+    ops.linear(x, a.weight, a.bias), ops.linear(x, b.weight, b.bias)
+    n_two = len(ops._packs.entries)
+    assert n_two >= 2
+    assert ops.repack_persistent([a.weight, a.bias]) < ops.repack_persistent()       # scoped < everything
+    del b
+    gc.collect()
+    assert len(ops._packs.entries) < n_two                       # b's entries went with b
+    y = ops.linear(x, a.weight, a.bias)
+    assert torch.allclose(y, torch.nn.functional.linear(x, a.weight, a.bias), rtol=1e-4, atol=1e-5)
