@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C3-large")
+    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+                    help="train (default): the headline metric, one step = reference train.py:66-75.  infer: the OTHER caller of "
+                         "the hot path, reference test.py:31-74 model_test -- eval-mode BatchNorm, no saved pre-activation, "
+                         "torch.no_grad, softmax / de-padding glue of evaluation.predict; one step = one batch")
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16", "bf16x3"],
                     help="arithmetic of the attention contractions (everything else is fp32): f32 = fp32 MFMA (default, BASELINE "
                          "config 3); bf16x3 = bf16 MFMA on hi/lo split operands, fp32-class accuracy (default for --workload "
@@ -261,10 +265,106 @@ def wait_for_ranks(procs, timeout, grace=10.0, out=sys.stderr):
     return worst
 
 
+def infer_cpu_baseline(dims, wl, seconds, cpu_batch):
+    """orc.model_test_scores (restatement of reference test.py:31-74, parity unpinned: see its docstring) on the host cores, on
+    a bounded sample of the same workload."""
+    from news_recommendation_model_amd import synth
+    from oracle import user_model_oracle as orc
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    per_imp = wl["T"] * wl["H"] * 4 * wl["emb"] * 4
+    Bc = cpu_batch or int(max(2, min(wl["B"], (256 << 20) // per_imp)))
+    batch = synth.make_batch(dims, Bc, wl["H"], wl["T"], seed=0)
+    sd = synth.make_state_dict(dims, seed=1, user_num=int(batch["user_num"]), perturb=False)
+    p = orc.to_torch_params(sd)
+    tb = {k: torch.from_numpy(v) for k, v in batch.items() if isinstance(v, np.ndarray) and v.ndim > 0}
+    tb = {k: (v.float() if v.is_floating_point() else v) for k, v in tb.items()}
+    tb["empty_num"] = torch.zeros(Bc, dtype=torch.int64)
+    orc.model_test_scores([p], tb)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.model_test_scores([p], tb)
+        n += 1
+        el = time.perf_counter() - t0
+        if (el >= seconds and n >= 3) or el > 3 * seconds:
+            break
+    return {"value": round(Bc * n / el, 2), "unit": "impressions/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/user_model_oracle.model_test_scores (one model), B={Bc} H={wl['H']} T={wl['T']} D={wl['emb']}, "
+                      f"{n} batches after 1 warm-up, torch CPU fp32 {cores} threads"}
+
+
+def main_infer(args):
+    """--mode infer: impressions/s of evaluation.predict([model], batch) -- reference test.py:31-74 -- on one GPU."""
+    if args.gpus != 1:
+        raise SystemExit("bench.py --mode infer runs on one GPU (impressions are independent: N replicas scale trivially)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from news_recommendation_model_amd import evaluation, native, synth, trainer
+    from news_recommendation_model_amd import ops as _ops
+    from news_recommendation_model_amd.config import Dims, WORKLOADS
+    native.load()
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl["B"] = args.batch
+    B, H, T, D = wl["B"], wl["H"], wl["T"], wl["emb"]
+    if args.dtype is None:
+        args.dtype = "bf16x3" if args.workload == "C2-small" else "f32"
+    dims = Dims.for_emb(D)
+    user_num = 10 * B
+    sd = synth.make_state_dict(dims, seed=1, user_num=user_num, perturb=False)
+    model = trainer.build_model(dims, user_num, sd, device=dev, attention_mma=args.dtype).eval()
+    batch = synth.make_batch(dims, B, H, T, seed=0, user_num=user_num, dtype=np.float32)
+    tb = trainer.batch_to_device(batch, dev)
+    tb["empty_num"] = torch.zeros(B, dtype=torch.int64, device=dev)          # throughput run: no padded candidates
+    models = [model]
+    for _ in range(max(args.warmup, 2)):
+        scores, live = evaluation.predict(models, tb)
+    torch.cuda.synchronize()
+    native.kernel_events = []
+    for _ in range(3):                                  # kernel table: untimed, bracketed
+        evaluation.predict(models, tb)
+    torch.cuda.synchronize()
+    events, native.kernel_events = native.kernel_events, None
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        scores, live = evaluation.predict(models, tb)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _ops.check_index_errors(dev)
+    per = {}
+    for tag, e0, e1 in events:
+        per.setdefault(tag, []).append(e0.elapsed_time(e1))
+    kern = {k: {"launches": len(v), "mean_ms": float(np.mean(v))} for k, v in per.items()}
+    fwd_ms = kern["nrm_pwattn_fwd"]["mean_ms"]
+    flops = 2.0 * B * T * H * D * D
+    peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
+    ach = flops / (fwd_ms * 1e-3) / 1e12
+    # without the z store the forward's algorithmic HBM bytes are its operands (t, h, u, v) and the scores: never the bound
+    roof = {"bound": "mfma", "kernel": "nrm_pwattn_fwd (no z store)", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "flops_per_launch": flops, "mean_launch_ms": round(fwd_ms, 4), "traffic": None,
+            "traffic_source": "no committed PMC profile for the inference forward"}
+    ms = elapsed / args.steps * 1e3
+    line = {"metric": "inference impressions/sec (reference test.py:31-74 model_test, one model)", "value": round(B * args.steps / elapsed, 2),
+            "unit": "impressions/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": args.workload, "mode": "infer", "batch": B, "hist": H, "candidates": T, "emb": D, "launch": "eager",
+                       "step": "evaluation.predict: trim + eval-mode forward (no saved z) + softmax + de-padding softmax"},
+            "roofline": roof,
+            "kernels": {k: {"launches": v["launches"], "mean_ms": round(v["mean_ms"], 4)} for k, v in kern.items()},
+            "gpu_kernel_ms_per_step": round(sum(v["mean_ms"] * v["launches"] for v in kern.values()) / 3, 4)}
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = infer_cpu_baseline(dims, wl, args.cpu_seconds, args.cpu_batch)
+    print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.mode == "infer":
+        return main_infer(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args.gpus, args.timeout)
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -89,6 +89,7 @@ class Dims:
 # BASELINE.json configs -> (B, H, T, emb)   (SURVEY §8d "Config -> shapes")
 WORKLOADS = {
     "ref-default": dict(B=256, H=200, T=15, emb=64),
+    "ref-test80": dict(B=80, H=200, T=15, emb=64),      # reference inference: model_test batches of 80 (train.py:107, verify.py:22)
     "C1-demo": dict(B=256, H=10, T=20, emb=256),
     "C2-small": dict(B=512, H=32, T=30, emb=256),
     "C3-large": dict(B=1024, H=50, T=30, emb=400),

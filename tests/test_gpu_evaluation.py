@@ -135,3 +135,43 @@ def test_train_epochs_raises_indexerror_for_an_out_of_range_id(lib):
     ops.check_index_errors("cuda")
     hosts[1]["x_history"][3, 2, cat_col] = 1
     assert len(trainer.train_epochs(model, opt, lambda: iter(hosts), 1)) == 1
+
+
+def test_full_size_inference_properties(lib):
+    """The inference path of reference test.py:31-74 at BASELINE C3 dimensions (B=1024, H=50, T=30, D=400: too big for the CPU
+    oracle as a whole): eval-mode BatchNorm makes impressions independent, so predict() of the batch must equal predict() of
+    its parts bit for bit (same kernels, no atomics in the fp32 forward without the z store), per-row padding triggers the
+    second softmax only on the rows that carry it, and two impressions match the oracle's model_test restatement."""
+    from news_recommendation_model_amd import evaluation, synth, trainer
+    from news_recommendation_model_amd.config import Dims
+    B, H, T, D = 1024, 50, 30, 400
+    dims = Dims.for_emb(D)
+    user_num = 10 * B
+    sd = synth.make_state_dict(dims, seed=1, user_num=user_num, perturb=True)
+    model = trainer.build_model(dims, user_num, sd, device="cuda").eval()
+    batch = synth.make_batch(dims, B, H, T, seed=3, user_num=user_num, dtype=np.float32)
+    empty = np.zeros(B, dtype=np.int64)
+    empty[5], empty[700] = 4, 9                                   # two rows with their own trailing padding
+    for b in (5, 700):
+        batch["x_target"][b, T - empty[b]:] = 0
+        batch["x_global"][b, T - empty[b]:] = 0
+    batch["empty_num"] = empty
+    tb = trainer.batch_to_device(batch, "cuda")
+    whole, live = evaluation.predict([model], tb)
+    assert whole.shape == (B, T) and int(live[5]) == T - 4 and int(live[700]) == T - 9 and int(live[0]) == T
+    part = lambda lo, hi: {k: (v[lo:hi] if hasattr(v, "shape") and v.ndim > 0 and v.shape[0] == B else v) for k, v in tb.items()}   # noqa: E731
+    lo, _ = evaluation.predict([model], part(0, 512))
+    hi, _ = evaluation.predict([model], part(512, B))
+    assert torch.equal(whole[:512], lo) and torch.equal(whole[512:], hi)
+    # every row is a distribution over its live candidates
+    cols = torch.arange(T, device="cuda")[None, :]
+    assert torch.allclose((whole * (cols < live[:, None])).sum(1), torch.ones(B, device="cuda"), atol=1e-5)
+    # spot check against the oracle: one plain row, one padded row (second softmax)
+    idx = [3, 700]
+    tbc = {k: torch.from_numpy(np.asarray(v)[idx]) for k, v in batch.items() if isinstance(v, np.ndarray) and v.ndim > 0}
+    ref = orc.model_test_scores([orc.to_torch_params(sd, False)], tbc)
+    # (the oracle trims the padding COMMON to its two rows first; the scores of the live candidates do not depend on it)
+    for j, b in enumerate(idx):
+        n = int(live[b])
+        assert len(ref[j]) == n
+        assert rel_err(whole[b, :n].cpu().numpy(), ref[j]) < 1e-3
