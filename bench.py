@@ -313,6 +313,8 @@ def main_infer(args):
         args.dtype = "bf16x3" if args.workload == "C2-small" else "f32"
     dims = Dims.for_emb(D)
     user_num = 10 * B
+    if args.dtype != "f32":
+        _ops.set_dense_arithmetic(args.dtype)
     sd = synth.make_state_dict(dims, seed=1, user_num=user_num, perturb=False)
     model = trainer.build_model(dims, user_num, sd, device=dev, attention_mma=args.dtype).eval()
     batch = synth.make_batch(dims, B, H, T, seed=0, user_num=user_num, dtype=np.float32)
@@ -417,6 +419,10 @@ def main():
         args.dtype = "bf16x3" if args.workload == "C2-small" else "f32"
     dims = Dims.for_emb(D)
     user_num = 10 * B
+    if args.dtype != "f32":
+        # BASELINE config 2 names bf16: the dense layers run on the bf16 matrix cores as well (same hi/lo split as the attention)
+        from news_recommendation_model_amd import ops as _o
+        _o.set_dense_arithmetic(args.dtype)
     # same weights on every rank (seed 1), a different batch per rank (seed = rank)
     sd = synth.make_state_dict(dims, seed=1, user_num=user_num, perturb=False)
     model = trainer.build_model(dims, user_num, sd, device=dev, attention_mma=args.dtype).train()
@@ -603,8 +609,8 @@ def main():
             "metric": "train impressions/sec", "value": round(world * B * args.steps / elapsed, 2),
             "unit": "impressions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16": "bf16 (attention contractions: bf16 MFMA operands, fp32 accumulate; rest f32)",
-                      "bf16x3": "bf16x3 (attention contractions: bf16 MFMA on hi/lo split operands, fp32 accumulate; rest f32)"}[args.dtype],
+            "dtype": {"f32": "f32", "bf16": "bf16 (attention contractions and dense GEMMs: bf16 MFMA operands, fp32 accumulate; rest f32)",
+                      "bf16x3": "bf16x3 (attention contractions and dense GEMMs: bf16 MFMA on hi/lo split operands, fp32 accumulate; rest f32)"}[args.dtype],
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: EBNeRD-large-shape synthetic" if args.workload == "C3-large" else args.workload,
                        "per_gpu_batch": B, "global_batch": world * B, "hist": H, "candidates": T, "emb": D,

@@ -101,7 +101,11 @@ int nrm_pwattn_bwd_rw_dtdh(const float* dz_hl4, const float* t, const float* h, 
 #define NRM_EPI_GELU 1   /* z = x W^T + bias (saved for backward), y = gelu(z)                            */
 #define NRM_EPI_DGELU 2  /* y = (x W^T) * gelu'(z)      (z = pre-activation saved by NRM_EPI_GELU)        */
 #define NRM_EPI_MUL 3    /* z = x W^T + bias (kept for backward), y = z * m: the gate of user_model.py:33 */
-long nrm_gemm_packed_floats(int nrows, int ncols);
+/* mma: the arithmetic the packed image is for (NRM_MMA_F32: the fp32 streaming layout of gemm_nt; NRM_MMA_BF16 / _BF16X3: bf16
+ * hi [+ lo] MFMA fragments).  Dense layers on the bf16 matrix cores (BASELINE config 2) keep fp32 accumulation, bias, GELU and
+ * column sums; nrm_gemm_nt_bf16_supported says whether a reduction width K fits the resident-row form (else use NRM_MMA_F32). */
+long nrm_gemm_packed_floats(int nrows, int ncols, int mma);
+int nrm_gemm_nt_bf16_supported(int M, int K, int mma);
 /* packs the logical [nrows x ncols] matrix src[r*row_stride + c*col_stride]; rows become output columns of
  * nrm_gemm_nt, columns its reduction index.  Linear.forward: (W[N,K], K, 1, N, K); dX = dY W: (W, 1, K, K, N) */
 int nrm_gemm_pack(const float* src, long row_stride, long col_stride, int nrows, int ncols, float* packed,
@@ -113,19 +117,20 @@ int nrm_gemm_pack(const float* src, long row_stride, long col_stride, int nrows,
 typedef struct {
     const float* src; const float* src2; float sign2;
     long row_stride, col_stride; int nrows, ncols;
-    float* packed;           /* nrm_gemm_packed_floats(nrows, ncols) floats */
+    float* packed;           /* nrm_gemm_packed_floats(nrows, ncols, mma) floats */
+    int mma;                 /* NRM_MMA_*: layout of the packed image */
 } nrm_pack_desc;
 int nrm_gemm_pack_multi(const nrm_pack_desc* descs, int n, nrm_stream_t stream);
 /* y[M, N] (ld ldy) = epilogue( x[M, K] (ld ldx) * packed^T ), bias [N] or NULL; m [M, N] (ld ldm) for NRM_EPI_MUL */
 int nrm_gemm_nt(const float* x, int ldx, int M, const float* packed, int N, int K, const float* bias,
-                float* y, int ldy, float* z, int ldz, const float* m, int ldm, int epilogue, nrm_stream_t stream);
+                float* y, int ldy, float* z, int ldz, const float* m, int ldm, int epilogue, int mma, nrm_stream_t stream);
 /* C[i,j] = sum_r A[r,i] B[r,j]  (dW = dY^T X): writes nsplit TRANSPOSED partial slabs ws[s][j][ldws] and, if
  * colsum != NULL, colsum[s][i] = sum_r A[r,i] (the bias gradient); sum over s.  ldws % 4 == 0, ldws >= ncols_i */
-int nrm_gemm_tn_nsplit(int ncols_i, int ncols_j, int R);
+int nrm_gemm_tn_nsplit(int ncols_i, int ncols_j, int R, int mma);
 /* zero_out (optional, 16-byte aligned): zero_n floats there are set to 0 by the same launch -- the gradient buffer that
  * nrm_slab_reduce will then add the slabs to */
 int nrm_gemm_tn(const float* A, int lda, int ncols_i, const float* B, int ldb, int ncols_j, int R,
-                float* ws, int ldws, float* colsum, float* zero_out, long zero_n, nrm_stream_t stream);
+                float* ws, int ldws, float* colsum, float* zero_out, long zero_n, int mma, nrm_stream_t stream);
 
 /* the split slabs ws[s][j][ldws] of nrm_gemm_tn / nrm_pwattn_bwd_contract summed over s and ADDED (float atomics; the
  * caller zero-initialises, or accumulates on purpose) where the gradient lives:

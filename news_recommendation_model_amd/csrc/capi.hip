@@ -52,7 +52,7 @@ extern "C" {
 
 int nrm_abi_version(void) { return NRM_ABI_VERSION; }
 int nrm_build_flags(void) { return nrm::pwattn_fwd_diag_flags() | nrm::pwattn_fwd_rw_diag_flags() | nrm::pwattn_bwd_diag_flags() |
-                                    nrm::pwattn_bwd_rw_diag_flags(); }
+                                    nrm::pwattn_bwd_rw_diag_flags() | nrm::gemm_bf16_diag_flags(); }
 const char* nrm_last_error(void) { return g_err; }
 
 long nrm_pwattn_packed_floats(int D) {
@@ -197,11 +197,15 @@ int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, con
 // ------------------------------------------------------------------------------------------- dense layers
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-long nrm_gemm_packed_floats(int nrows, int ncols) {
+long nrm_gemm_packed_floats(int nrows, int ncols, int mma) {
     if (nrows <= 0 || ncols <= 0) return 0;
+    if (mma == NRM_MMA_BF16 || mma == NRM_MMA_BF16X3)                    // weight fragments of gemm_nt_rx: 1 KiB per (tile, chunk, image)
+        return (long)((nrows + 15) / 16) * ((ncols + 31) / 32) * (mma == NRM_MMA_BF16X3 ? 2 : 1) * 256 + 1024;
     const nrm::GemmNtPlan pl = nrm::gemm_nt_plan(nrows);
     return (long)((ncols + 15) / 16) * pl.rows * 16 + 1024;
 }
+
+int nrm_gemm_nt_bf16_supported(int M, int K, int mma) { return nrm::gemm_nt_rx_bm(M, K, mma) ? 1 : 0; }
 
 int nrm_gemm_pack(const float* src, long row_stride, long col_stride, int nrows, int ncols, float* packed,
                   nrm_stream_t stream) {
@@ -223,8 +227,11 @@ int nrm_gemm_pack_multi(const nrm_pack_desc* descs, int n, nrm_stream_t stream) 
             const nrm::GemmNtPlan pl = nrm::gemm_nt_plan(d.nrows);
             nrm::PackEntry& e = tab.e[i];
             e.src = d.src; e.src2 = d.src2; e.dst = d.packed; e.rs = d.row_stride; e.cs = d.col_stride;
-            e.nrows = d.nrows; e.ncols = d.ncols; e.rows = pl.rows; e.kchunks = (d.ncols + 15) / 16; e.sign2 = d.sign2;
-            const long total = (long)e.kchunks * e.rows * 16;
+            e.nrows = d.nrows; e.ncols = d.ncols; e.rows = pl.rows; e.kchunks = (d.ncols + 15) / 16; e.sign2 = d.sign2; e.fmt = 0;
+            if (d.mma == NRM_MMA_BF16 || d.mma == NRM_MMA_BF16X3) {
+                e.fmt = d.mma == NRM_MMA_BF16X3 ? 2 : 1; e.rows = (d.nrows + 15) / 16 * 16; e.kchunks = (d.ncols + 31) / 32;
+            } else if (d.mma != NRM_MMA_F32) return fail(NRM_EINVAL, "nrm_gemm_pack_multi: entry %d: mma=%d", lo + i, d.mma);
+            const long total = e.fmt ? (long)(e.rows / 16) * e.kchunks * 512 : (long)e.kchunks * e.rows * 16;
             if (total > mx) mx = total;
         }
         if (int rc = check_hip(nrm::pack_rows_multi_launch(tab, m, mx, (hipStream_t)stream), "pack_rows_multi")) return rc;
@@ -233,7 +240,7 @@ int nrm_gemm_pack_multi(const nrm_pack_desc* descs, int n, nrm_stream_t stream) 
 }
 
 int nrm_gemm_nt(const float* x, int ldx, int M, const float* packed, int N, int K, const float* bias,
-                float* y, int ldy, float* z, int ldz, const float* m, int ldm, int epilogue, nrm_stream_t stream) {
+                float* y, int ldy, float* z, int ldz, const float* m, int ldm, int epilogue, int mma, nrm_stream_t stream) {
     if (!x || !packed || !y) return fail(NRM_EINVAL, "nrm_gemm_nt: null pointer");
     if (M < 0 || N <= 0 || K <= 0) return fail(NRM_EINVAL, "nrm_gemm_nt: M=%d N=%d K=%d", M, N, K);
     if (ldx % 4 || ldy % 4 || ldx < K || ldy < N || !al16(x) || !al16(y))
@@ -244,9 +251,20 @@ int nrm_gemm_nt(const float* x, int ldx, int M, const float* packed, int N, int 
     if (epilogue == NRM_EPI_MUL && (!m || ldm % 4 || ldm < N || !al16(m)))
         return fail(NRM_EINVAL, "nrm_gemm_nt: NRM_EPI_MUL needs m with ldm %% 4 == 0, ldm >= N");
     if ((long)256 * (ldx > ldy ? ldx : ldy) * 4 >= (1L << 31)) return fail(NRM_EINVAL, "nrm_gemm_nt: leading dimension too large");
+    if (int rc = check_mma("nrm_gemm_nt", mma)) return rc;
+    if (mma != NRM_MMA_F32) {                                          // bf16 matrix cores: resident-X form (gemm_bf16.hip)
+        if (!nrm::gemm_nt_rx_bm(M > 0 ? M : 1, K, mma)) return fail(NRM_EINVAL, "nrm_gemm_nt: K=%d is too wide for the bf16 form (nrm_gemm_nt_bf16_supported)", K);
+        nrm::GemmRxParams r = {};
+        r.x = x; r.ldx = ldx; r.xcols = ldx; r.wq = packed; r.wq_bytes = (unsigned)(nrm_gemm_packed_floats(N, K, mma) * 4);
+        r.bias = bias; r.N = N; r.y = y; r.ldy = ldy;
+        r.z = epilogue == NRM_EPI_BIAS ? nullptr : z; r.ldz = epilogue == NRM_EPI_BIAS ? 4 : ldz;
+        r.m = epilogue == NRM_EPI_MUL ? m : nullptr; r.ldm = epilogue == NRM_EPI_MUL ? ldm : 4;
+        r.M = M; r.K = K; r.k32 = (K + 31) / 32; r.nt16 = (N + 15) / 16;
+        return check_hip(nrm::gemm_nt_rx_launch(r, epilogue, mma, (hipStream_t)stream), "gemm_nt_rx");
+    }
     const nrm::GemmNtPlan pl = nrm::gemm_nt_plan(N);
     nrm::GemmNtParams p;
-    p.x = x; p.ldx = ldx; p.xcols = ldx; p.wp = packed; p.wp_bytes = (unsigned)(nrm_gemm_packed_floats(N, K) * 4);
+    p.x = x; p.ldx = ldx; p.xcols = ldx; p.wp = packed; p.wp_bytes = (unsigned)(nrm_gemm_packed_floats(N, K, NRM_MMA_F32) * 4);
     p.rows = pl.rows; p.bias = bias; p.N = N; p.y = y; p.ldy = ldy;
     p.z = epilogue == NRM_EPI_BIAS ? nullptr : z; p.ldz = epilogue == NRM_EPI_BIAS ? 4 : ldz;
     p.m = epilogue == NRM_EPI_MUL ? m : nullptr; p.ldm = epilogue == NRM_EPI_MUL ? ldm : 4;
@@ -259,24 +277,28 @@ static int tn_waves() {
     return kTnWaves;
 }
 
-int nrm_gemm_tn_nsplit(int ncols_i, int ncols_j, int R) {
+int nrm_gemm_tn_nsplit(int ncols_i, int ncols_j, int R, int mma) {
     if (ncols_i <= 0 || ncols_j <= 0 || R <= 0) return 0;
-    return nrm::gemm_tn_plan(ncols_i, ncols_j, R, tn_waves()).nsplit;
+    return nrm::gemm_tn_plan(ncols_i, ncols_j, R, tn_waves(), mma).nsplit;
 }
 
 int nrm_gemm_tn(const float* A, int lda, int ncols_i, const float* B, int ldb, int ncols_j, int R,
-                float* ws, int ldws, float* colsum, float* zero_out, long zero_n, nrm_stream_t stream) {
+                float* ws, int ldws, float* colsum, float* zero_out, long zero_n, int mma, nrm_stream_t stream) {
     if (!A || !B || !ws) return fail(NRM_EINVAL, "nrm_gemm_tn: null pointer");
     if (ncols_i <= 0 || ncols_j <= 0 || R <= 0 || lda < ncols_i || ldb < ncols_j)
         return fail(NRM_EINVAL, "nrm_gemm_tn: ncols_i=%d ncols_j=%d R=%d lda=%d ldb=%d", ncols_i, ncols_j, R, lda, ldb);
     if (ldws % 4 || ldws < ncols_i || !al16(ws)) return fail(NRM_EINVAL, "nrm_gemm_tn: ldws=%d", ldws);
-    const nrm::GemmTnPlan pl = nrm::gemm_tn_plan(ncols_i, ncols_j, R, tn_waves());
+    if (int rc = check_mma("nrm_gemm_tn", mma)) return rc;
+    const nrm::GemmTnPlan pl = nrm::gemm_tn_plan(ncols_i, ncols_j, R, tn_waves(), mma);
     if ((long)pl.rps * (lda > ldb ? lda : ldb) * 4 >= (1L << 31)) return fail(NRM_EINVAL, "nrm_gemm_tn: split too large");
+    if (mma != NRM_MMA_F32 && (lda % 4 || ldb % 4 || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)))
+        return fail(NRM_EINVAL, "nrm_gemm_tn: the bf16 forms read 16-byte row segments (lda, ldb multiples of 4, 16-byte aligned rows)");
     nrm::GemmTnParams p = {};
     p.A = A; p.lda = lda; p.acols = lda; p.B = B; p.ldb = ldb; p.bcols = ldb;
     if (zero_out && (zero_n < 0 || !al16(zero_out))) return fail(NRM_EINVAL, "nrm_gemm_tn: zero_out must be 16-byte aligned, zero_n >= 0");
     p.ws = ws; p.ldws = ldws; p.colsum = colsum; p.R = R; p.ncols_j = ncols_j;
     p.zero_out = zero_out; p.zero_n = zero_out ? zero_n : 0;
+    if (mma != NRM_MMA_F32) return check_hip(nrm::gemm_tn_bf16_launch(p, pl, mma, (hipStream_t)stream), "gemm_tn_bf16");
     return check_hip(nrm::gemm_tn_launch(p, pl, (hipStream_t)stream), "gemm_tn");
 }
 

@@ -39,6 +39,29 @@ __global__ void pack_rows_kernel(const float* __restrict__ src, long rs, long cs
 // W_t + W_d (pwattn_fwd.hip), formed here instead of by separate elementwise launches.
 __global__ __launch_bounds__(256) void pack_rows_multi_kernel(const PackTable tab) {
     const PackEntry e = tab.e[blockIdx.y];
+    if (e.fmt) {
+        // weight fragments of gemm_nt_rx: dst[it][c][img][r16][32 bf16], element (n = 16 it + r16, k = 32 c + j)
+        const int nimg = e.fmt;
+        const long total = (long)(e.rows / 16) * e.kchunks * 512;
+        __bf16* dst = reinterpret_cast<__bf16*>(e.dst);
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            const int j = (int)(i & 31), r16 = (int)((i >> 5) & 15);
+            const long tc = i >> 9;                                      // it * kchunks + c
+            const int c = (int)(tc % e.kchunks), it = (int)(tc / e.kchunks);
+            const int n = 16 * it + r16, k = 32 * c + j;
+            float v = 0.0f;
+            if (n < e.nrows && k < e.ncols) {
+                const long o = n * e.rs + k * e.cs;
+                v = e.src[o];
+                if (e.src2) v = fmaf(e.sign2, e.src2[o], v);
+            }
+            const __bf16 hi = (__bf16)v;
+            const long o = (tc * nimg) * 512 + r16 * 32 + j;
+            dst[o] = hi;
+            if (nimg > 1) dst[o + 512] = (__bf16)(v - (float)hi);
+        }
+        return;
+    }
     const long total = (long)e.kchunks * e.rows * 16;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int j = (int)(i & 15);
@@ -388,12 +411,13 @@ __global__ __launch_bounds__(256, KT == 4 ? 4 : 3) void gemm_tn_kernel(const Gem
 #endif
 }
 
-GemmTnPlan gemm_tn_plan(int ncols_i, int ncols_j, int R, int target_waves) {
+GemmTnPlan gemm_tn_plan(int ncols_i, int ncols_j, int R, int target_waves, int mma) {
     GemmTnPlan pl;
     const int ni16 = (ncols_i + 15) / 16, nj16 = (ncols_j + 15) / 16;
     // 5x5 or 4x4 tiles of 16: the shape with fewer padded tiles
     const long w5 = (long)((ni16 + 4) / 5) * ((nj16 + 4) / 5) * 25, w4 = (long)((ni16 + 3) / 4) * ((nj16 + 3) / 4) * 16;
     pl.T = w5 <= w4 ? 5 : 4;
+    if (mma) pl.T = 4;                              // bf16 forms (gemm_bf16.hip): 4x4 tiles, 32-row super-steps
     pl.nti = (ni16 + pl.T - 1) / pl.T;
     pl.ntj = (nj16 + pl.T - 1) / pl.T;
     const int tiles = pl.nti * pl.ntj;
@@ -405,6 +429,7 @@ GemmTnPlan gemm_tn_plan(int ncols_i, int ncols_j, int R, int target_waves) {
     const int max_ns = (R + 127) / 128;
     if (ns > max_ns) ns = max_ns < 1 ? 1 : max_ns;
     pl.rps = ((R + ns - 1) / ns + 3) / 4 * 4;        // multiple of 4 rows
+    if (mma) pl.rps = (pl.rps + 31) / 32 * 32;       // whole 32-row MFMA steps
     if (pl.rps < 4) pl.rps = 4;
     pl.nsplit = (R + pl.rps - 1) / pl.rps;
     if (pl.nsplit < 1) pl.nsplit = 1;

@@ -22,8 +22,24 @@ hipError_t gemm_nt_launch(const GemmNtParams& p, const GemmNtPlan& pl, int epi, 
 hipError_t pack_rows_launch(const float* src, long rs, long cs, int nrows, int ncols, int rows, int kchunks,
                             float* packed, hipStream_t st);
 
-constexpr int PACK_MAX = 40;
-struct PackEntry { const float* src; const float* src2; float* dst; long rs, cs; int nrows, ncols, rows, kchunks; float sign2; };
+// gemm_nt_rx (gemm_bf16.hip): the bf16 / bf16x3 forward GEMM with the workgroup's X rows resident in LDS
+struct GemmRxParams {
+    const float* x; int ldx, xcols;       // [M, ldx]
+    const float* wq; unsigned wq_bytes;   // weight fragments wq[it][c][img][16][32 bf16] (PackEntry fmt 1 | 2)
+    const float* bias; int N;
+    float* y; int ldy;
+    float* z; int ldz;
+    const float* m; int ldm;
+    int M, K, k32, nt16;                  // k32 = ceil(K / 32) reduction chunks, nt16 = ceil(N / 16) output-column tiles
+};
+int gemm_bf16_diag_flags();                                // bit 10: NRM_DIAG_RX (timing-only build)
+int gemm_nt_rx_bm(int M, int K, int mma);                  // rows per workgroup; 0: K too wide (the caller keeps the fp32 GEMM)
+hipError_t gemm_nt_rx_launch(const GemmRxParams& p, int epi, int mma, hipStream_t st);
+
+constexpr int PACK_MAX = 36;
+// fmt 0: the fp32 image of gemm_nt (rows / kchunks as planned); fmt 1 | 2: bf16 hi [+ lo] weight fragments of gemm_nt_rx
+// (rows = 16 * ceil(nrows / 16), kchunks = ceil(ncols / 32))
+struct PackEntry { const float* src; const float* src2; float* dst; long rs, cs; int nrows, ncols, rows, kchunks; float sign2; int fmt; };
 struct PackTable { PackEntry e[PACK_MAX]; };          // 40 x 64 B of kernel arguments
 hipError_t pack_rows_multi_launch(const PackTable& tab, int n, long max_total, hipStream_t st);
 
@@ -37,8 +53,9 @@ struct GemmTnParams {
     int nti, nsplit, rps;                 // filled by gemm_tn_launch from the plan
 };
 struct GemmTnPlan { int T, nti, ntj, nsplit, rps; };
-GemmTnPlan gemm_tn_plan(int ncols_i, int ncols_j, int R, int target_waves);
+GemmTnPlan gemm_tn_plan(int ncols_i, int ncols_j, int R, int target_waves, int mma = 0);
 hipError_t gemm_tn_launch(GemmTnParams p, const GemmTnPlan& pl, hipStream_t st);
+hipError_t gemm_tn_bf16_launch(GemmTnParams p, const GemmTnPlan& pl, int mma, hipStream_t st);      // gemm_bf16.hip
 
 // out[i*ors + j*ocs] += sum_s ws[s][j][i] (i < ni, j < nj): the split slabs of gemm_tn / the dW_p pass summed and
 // ADDED where the gradient lives (any strides: straight or transposed, or a column block of a wider matrix; float

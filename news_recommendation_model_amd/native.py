@@ -31,15 +31,16 @@ SIGNATURES = {
     "nrm_pwattn_bwd_rw_dtdh": (_c_i, [_c_fp] * 6 + [_c_i] * 5 + [_c_fp]),
     "nrm_pwattn_bwd_nsplit": (_c_i, [_c_i] * 5),
     "nrm_pwattn_bwd_contract": (_c_i, [_c_fp] * 4 + [_c_i] + [_c_fp] * 3 + [_c_i] * 7 + [_c_fp]),
-    "nrm_gemm_packed_floats": (_c_l, [_c_i, _c_i]),
+    "nrm_gemm_packed_floats": (_c_l, [_c_i, _c_i, _c_i]),
+    "nrm_gemm_nt_bf16_supported": (_c_i, [_c_i, _c_i, _c_i]),
     "nrm_gemm_pack": (_c_i, [_c_fp, _c_l, _c_l, _c_i, _c_i, _c_fp, _c_fp]),
-    "nrm_gemm_nt": (_c_i, [_c_fp, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_fp, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_i, _c_fp]),
+    "nrm_gemm_nt": (_c_i, [_c_fp, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_fp, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_i, _c_i, _c_fp]),
     "nrm_slab_reduce": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_fp, _c_l, _c_l, _c_fp, _c_l, _c_l, ctypes.c_float,
                                _c_fp, _c_fp, _c_fp]),
     "nrm_bn_finalize": (_c_i, [_c_i, _c_fp, _c_fp, _c_fp, _c_i, _c_i, ctypes.c_float, ctypes.c_float, _c_fp]),
     "nrm_mul_bwd": (_c_i, [_c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_fp, _c_i, _c_i, _c_i, _c_fp]),
-    "nrm_gemm_tn_nsplit": (_c_i, [_c_i, _c_i, _c_i]),
-    "nrm_gemm_tn": (_c_i, [_c_fp, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_fp, _c_l, _c_fp]),
+    "nrm_gemm_tn_nsplit": (_c_i, [_c_i, _c_i, _c_i, _c_i]),
+    "nrm_gemm_tn": (_c_i, [_c_fp, _c_i, _c_i, _c_fp, _c_i, _c_i, _c_i, _c_fp, _c_i, _c_fp, _c_fp, _c_l, _c_i, _c_fp]),
     "nrm_gemm_pack_multi": (_c_i, [_c_fp, _c_i, _c_fp]),
     "nrm_slab_reduce_multi": (_c_i, [_c_fp, _c_i, _c_fp]),
     "nrm_colreduce": (_c_i, [_c_i] + [_c_fp] * 6 + [_c_i] * 3 + [_c_fp]),
@@ -66,7 +67,7 @@ class PackDesc(ctypes.Structure):
     """nrm_pack_desc of include/nrm_hotpath.h"""
     _fields_ = [("src", ctypes.c_void_p), ("src2", ctypes.c_void_p), ("sign2", ctypes.c_float),
                 ("row_stride", ctypes.c_long), ("col_stride", ctypes.c_long), ("nrows", ctypes.c_int), ("ncols", ctypes.c_int),
-                ("packed", ctypes.c_void_p)]
+                ("packed", ctypes.c_void_p), ("mma", ctypes.c_int)]
 
 
 class SlabDesc(ctypes.Structure):

@@ -36,6 +36,18 @@ def resolve_mma(mma):
     return int(mma)
 
 
+_default_dense_mma = MMA_F32
+
+
+def set_dense_arithmetic(mma):
+    """Process-wide arithmetic of the dense layers (Linear / MLP / BatchNorm gate GEMMs, w1): 'f32' (default: fp32 MFMA, BASELINE
+    config 3) or 'bf16x3' / 'bf16' (bf16 matrix cores with fp32 accumulation, bias and GELU -- BASELINE config 2; GEMMs whose
+    reduction width does not fit the resident-row kernel stay fp32).  The attention's own side projections follow the
+    attention's arithmetic."""
+    global _default_dense_mma
+    _default_dense_mma = resolve_mma(mma) if mma is not None else MMA_F32
+
+
 def set_attention_arithmetic(mma):
     """Process-wide default for attentions that do not carry their own ``mma`` attribute: 'f32' (BASELINE config 3,
     the default), 'bf16' (bf16 MFMA operands, fp32 accumulation) or 'bf16x3' (bf16 MFMA with hi/lo split operands:
@@ -114,29 +126,30 @@ class _PackEntry:
 _packs = _PackedWeights()
 
 
-def _pack_desc(src, rs, cs, nrows, ncols, src2, sign2, buf):
+def _pack_desc(src, rs, cs, nrows, ncols, src2, sign2, buf, mma=MMA_F32):
     return native.PackDesc(src.data_ptr(), src2.data_ptr() if src2 is not None else None, float(sign2), int(rs), int(cs),
-                           int(nrows), int(ncols), buf.data_ptr())
+                           int(nrows), int(ncols), buf.data_ptr(), int(mma))
 
 
 def _pack_desc_of(ent, owner):
     """Descriptor of a cached entry, addresses taken from its live owner (byte offsets were stored, not views)."""
-    off, rs, cs, nrows, ncols, off2, sign2 = ent.spec
+    off, rs, cs, nrows, ncols, off2, sign2, mma = ent.spec
     base = owner.data_ptr()
     return native.PackDesc(base + off, (base + off2) if off2 is not None else None, float(sign2), int(rs), int(cs),
-                           int(nrows), int(ncols), ent.buf.data_ptr())
+                           int(nrows), int(ncols), ent.buf.data_ptr(), int(mma))
 
 
-def _pack(src, rs, cs, nrows, ncols, src2=None, sign2=0.0, owner=None):
-    """Packed image of the logical [nrows x ncols] matrix src[r*rs + c*cs] (+ sign2 * src2[same]); see _PackedWeights."""
+def _pack(src, rs, cs, nrows, ncols, src2=None, sign2=0.0, owner=None, mma=MMA_F32):
+    """Packed image of the logical [nrows x ncols] matrix src[r*rs + c*cs] (+ sign2 * src2[same]) for the given arithmetic (fp32
+    streaming layout, or bf16 hi [+ lo] MFMA fragments); see _PackedWeights."""
     import weakref
     lib = native.load()
     if owner is None:
-        buf = torch.empty(lib.nrm_gemm_packed_floats(nrows, ncols), dtype=torch.float32, device=src.device)
-        d = _pack_desc(src, rs, cs, nrows, ncols, src2, sign2, buf)
+        buf = torch.empty(lib.nrm_gemm_packed_floats(nrows, ncols, mma), dtype=torch.float32, device=src.device)
+        d = _pack_desc(src, rs, cs, nrows, ncols, src2, sign2, buf, mma)
         native.call("nrm_gemm_pack_multi", _ctypes_ref(d), 1, native.stream_ptr())
         return buf
-    key = (src.data_ptr(), int(rs), int(cs), int(nrows), int(ncols), src2.data_ptr() if src2 is not None else 0, float(sign2))
+    key = (src.data_ptr(), int(rs), int(cs), int(nrows), int(ncols), src2.data_ptr() if src2 is not None else 0, float(sign2), int(mma))
     ent = _packs.entries.get(key)
     if ent is not None and (ent.owner() is not owner or ent.owner_ptr != owner.data_ptr()):
         ent = None                                                   # the address now belongs to another tensor
@@ -144,14 +157,14 @@ def _pack(src, rs, cs, nrows, ncols, src2=None, sign2=0.0, owner=None):
         return ent.buf
     if ent is None:
         ent = _PackEntry()
-        ent.buf = torch.empty(lib.nrm_gemm_packed_floats(nrows, ncols), dtype=torch.float32, device=src.device)
+        ent.buf = torch.empty(lib.nrm_gemm_packed_floats(nrows, ncols, mma), dtype=torch.float32, device=src.device)
         ent.owner, ent.owner_ptr = weakref.ref(owner), owner.data_ptr()
         # the views are rebuilt from the live owner when needed (a stored view would keep a dead model's storage alive)
         ent.spec = (src.data_ptr() - owner.data_ptr(), rs, cs, nrows, ncols,
-                    (src2.data_ptr() - owner.data_ptr()) if src2 is not None else None, sign2)
+                    (src2.data_ptr() - owner.data_ptr()) if src2 is not None else None, sign2, mma)
         _packs.entries[key] = ent
         weakref.finalize(owner, _packs.entries.pop, key, None)     # the entry goes when its parameter goes
-    d = _pack_desc(src, rs, cs, nrows, ncols, src2, sign2, ent.buf)
+    d = _pack_desc(src, rs, cs, nrows, ncols, src2, sign2, ent.buf, mma)
     native.call("nrm_gemm_pack_multi", _ctypes_ref(d), 1, native.stream_ptr())
     ent.version, ent.epoch = owner._version, _packs.epoch
     return ent.buf
@@ -196,12 +209,24 @@ def invalidate_packed_weights():
     _packs.epoch += 1
 
 
-def _gemm_nt(x, w_src, row_stride, col_stride, n_out, k_red, bias, epilogue, z=None, m=None, src2=None, sign2=0.0, owner=None):
+def _dense_mma(M, K, mma):
+    """The arithmetic a dense GEMM with M rows and reduction width K really runs in: ``mma`` (None = the process default of
+    ``set_dense_arithmetic``) if the bf16 resident-row form takes that K, else fp32."""
+    mma = _default_dense_mma if mma is None else mma
+    if mma != MMA_F32 and not native.load().nrm_gemm_nt_bf16_supported(int(M), int(K), int(mma)):
+        return MMA_F32
+    return mma
+
+
+def _gemm_nt(x, w_src, row_stride, col_stride, n_out, k_red, bias, epilogue, z=None, m=None, src2=None, sign2=0.0, owner=None,
+             mma=None):
     """y[M, n_out] = epilogue(x[M, k_red] * Wlogical^T), Wlogical[r, c] = w_src[r*row_stride + c*col_stride]
-    (+ sign2 * src2[same]); ``owner`` = the parameter w_src is a view of (its packed image is then cached)."""
+    (+ sign2 * src2[same]); ``owner`` = the parameter w_src is a view of (its packed image is then cached); ``mma``: arithmetic
+    of the products (None = the dense default)."""
     st = native.stream_ptr()
     M = x.shape[0]
-    packed = _pack(w_src, row_stride, col_stride, n_out, k_red, src2, sign2, owner)
+    mma = _dense_mma(M, k_red, mma)
+    packed = _pack(w_src, row_stride, col_stride, n_out, k_red, src2, sign2, owner, mma)
     ldy = _pad4(n_out)
     y = torch.empty(M, ldy, dtype=torch.float32, device=x.device)
     if epilogue in (EPI_GELU, EPI_MUL):
@@ -209,24 +234,27 @@ def _gemm_nt(x, w_src, row_stride, col_stride, n_out, k_red, bias, epilogue, z=N
     native.call("nrm_gemm_nt", native.ptr(x), x.stride(0), M, native.ptr(packed), n_out, k_red,
                 native.ptr(bias) if bias is not None else None, native.ptr(y), ldy,
                 native.ptr(z) if z is not None else None, z.stride(0) if z is not None else 0,
-                native.ptr(m) if m is not None else None, m.stride(0) if m is not None else 0, epilogue, st)
+                native.ptr(m) if m is not None else None, m.stride(0) if m is not None else 0, epilogue, mma, st)
     return y[:, :n_out], (z[:, :n_out] if epilogue in (EPI_GELU, EPI_MUL) else None)
 
 
-def _gemm_tn_slabs(a, b, want_colsum, zero_out=None):
+def _gemm_tn_slabs(a, b, want_colsum, zero_out=None, mma=None):
     """Partial slabs of (sum_r a[r,i] b[r,j]): ws[s][j][ldws] (TRANSPOSED) and the per-split column sums of a; ``zero_out``
-    (the buffer the slab reduction will add to) is zeroed by the same launch."""
+    (the buffer the slab reduction will add to) is zeroed by the same launch.  ``mma``: arithmetic (None = the dense default)."""
     lib = native.load()
     R, ni = a.shape
     nj = b.shape[1]
-    nsplit = lib.nrm_gemm_tn_nsplit(ni, nj, R)
+    mma = _default_dense_mma if mma is None else mma
+    if mma != MMA_F32 and (a.stride(0) % 4 or b.stride(0) % 4 or a.data_ptr() % 16 or b.data_ptr() % 16):
+        mma = MMA_F32                                   # the bf16 forms read 16-byte row segments
+    nsplit = lib.nrm_gemm_tn_nsplit(ni, nj, R, mma)
     ldws = _pad4(ni)
     ws = torch.empty(nsplit, nj, ldws, dtype=torch.float32, device=a.device)
     cs = torch.empty(nsplit, ldws, dtype=torch.float32, device=a.device) if want_colsum else None
     native.call("nrm_gemm_tn", native.ptr(a), a.stride(0), ni, native.ptr(b), b.stride(0), nj, R,
                 native.ptr(ws), ldws, native.ptr(cs) if cs is not None else None,
                 native.ptr(zero_out) if zero_out is not None else None, zero_out.numel() if zero_out is not None else 0,
-                native.stream_ptr())
+                mma, native.stream_ptr())
     return ws, cs, nsplit, ldws
 
 
@@ -363,14 +391,14 @@ def _join_wgrad_stream():
     _wgrad["used"].clear()
 
 
-def _gemm_tn(a, b, want_colsum, target=None):
+def _gemm_tn(a, b, want_colsum, target=None, mma=None):
     """(sum_r a[r,i] b[r,j]) as a contiguous [ni, nj], and optionally sum_r a[r,i]: the split-M GEMM plus ONE
     reduce+transpose launch that writes the gradient in place (no ATen sum/t/contiguous)."""
     ni, nj = a.shape[1], b.shape[1]
     ctx = _wgrad_stream(a, b)
     with ctx as side:
         c = torch.empty(ni, nj, dtype=torch.float32, device=a.device)      # zeroed by the GEMM launch itself
-        ws, cs, nsplit, ldws = _gemm_tn_slabs(a, b, want_colsum, zero_out=c)
+        ws, cs, nsplit, ldws = _gemm_tn_slabs(a, b, want_colsum, zero_out=c, mma=mma)
         colsum = torch.empty(ni, dtype=torch.float32, device=a.device) if want_colsum else None
         _slab_reduce(ws, nsplit, nj, ldws, ni, c, nj, 1, vec=cs, vec_out=colsum, target=target)
         if side:                                           # read (reduced, gathered) and released on the main stream after the join
@@ -407,8 +435,8 @@ def _pwattn_fwd_impl(t, h, w1, b1, w2, b2, save_z, mma):
     # side projections u = h (W_h - W_d)^T + b1, v = t (W_t + W_d)^T: the difference / sum is formed by the pack kernel
     own = w1 if w1 is w1_arg else None
     w_h, w_t, w_d = w1[:, :D], w1[:, D:2 * D], w1[:, 2 * D:3 * D]
-    u, _ = _gemm_nt(h.reshape(B * H, D), w_h, 4 * D, 1, D, D, b1, EPI_BIAS, src2=w_d, sign2=-1.0, owner=own)     # [B*H, D]
-    v, _ = _gemm_nt(t.reshape(B * T, D), w_t, 4 * D, 1, D, D, None, EPI_BIAS, src2=w_d, sign2=1.0, owner=own)   # [B*T, D]
+    u, _ = _gemm_nt(h.reshape(B * H, D), w_h, 4 * D, 1, D, D, b1, EPI_BIAS, src2=w_d, sign2=-1.0, owner=own, mma=mma)     # [B*H, D]
+    v, _ = _gemm_nt(t.reshape(B * T, D), w_t, 4 * D, 1, D, D, None, EPI_BIAS, src2=w_d, sign2=1.0, owner=own, mma=mma)   # [B*T, D]
     st = native.stream_ptr()
     packed = torch.empty(native.load().nrm_pwattn_packed_floats(D), dtype=torch.float32, device=t.device)
     native.call("nrm_pwattn_pack_wp", native.ptr(w1), 4 * D, D, mma, native.ptr(packed), st)
@@ -462,17 +490,17 @@ def _pwattn_bwd_impl(ds, t, h, w1, w2, z, mma):
     h2, t2 = h.reshape(B * H, D), t.reshape(B * T, D)
     ctx = _wgrad_stream(du2, h2, dv2, t2, dw1)          # (big batches under train_step: on the weight-gradient stream)
     with ctx as side:
-        ws, cs, ns, ldws = _gemm_tn_slabs(du2, h2, True, zero_out=dw1)  # du^T h, db1 = column sums of du
+        ws, cs, ns, ldws = _gemm_tn_slabs(du2, h2, True, zero_out=dw1, mma=mma)  # du^T h, db1 = column sums of du
         _slab_reduce(ws, ns, D, ldws, D, dw1, 4 * D, 1, out2=dw1[:, 2 * D:], out2_is=4 * D, out2_js=1, sign2=-1.0,
                      vec=cs, vec_out=db1, target=w1_arg)
-        ws2, _, ns, ldws = _gemm_tn_slabs(dv2, t2, False)
+        ws2, _, ns, ldws = _gemm_tn_slabs(dv2, t2, False, mma=mma)
         _slab_reduce(ws2, ns, D, ldws, D, dw1[:, D:], 4 * D, 1, out2=dw1[:, 2 * D:], out2_is=4 * D, out2_js=1, sign2=1.0, target=w1_arg)
         if side:
             for x in (ws, cs, ws2):
                 x.record_stream(ctx.main)
     # du (W_h - W_d), dv (W_t + W_d): the transposed orientation of the same two combinations   (D % 4 == 0: contiguous results)
-    dh = _gemm_nt(du2, w_h, 1, 4 * D, D, D, None, EPI_BIAS, src2=w_d, sign2=-1.0, owner=own)[0].reshape(B, H, D)
-    dt = _gemm_nt(dv2, w_t, 1, 4 * D, D, D, None, EPI_BIAS, src2=w_d, sign2=1.0, owner=own)[0].reshape(B, T, D)
+    dh = _gemm_nt(du2, w_h, 1, 4 * D, D, D, None, EPI_BIAS, src2=w_d, sign2=-1.0, owner=own, mma=mma)[0].reshape(B, H, D)
+    dt = _gemm_nt(dv2, w_t, 1, 4 * D, D, D, None, EPI_BIAS, src2=w_d, sign2=1.0, owner=own, mma=mma)[0].reshape(B, T, D)
     nsplit = lib.nrm_pwattn_bwd_nsplit(B, T, H, D, mma)
     wsp = torch.empty(nsplit, D, D, dtype=torch.float32, device=dev)
     wp = w1[:, 3 * D:]                                   # view, row stride 4D

@@ -202,3 +202,78 @@ def test_slab_reduce_multi_matches_single_launches_and_numpy(lib):
             vref = cs.astype(np.float64).sum(0)[:ni]
             for v in (v1, v2, v3):
                 assert np.abs(v - vref).max() <= 2e-6 * (np.abs(vref).max() + 1e-30) * max(1, nsplit) ** 0.5
+
+
+@pytest.fixture
+def dense_arithmetic():
+    """ops.set_dense_arithmetic for one test, restored afterwards."""
+    from news_recommendation_model_amd import ops
+    prev = ops._default_dense_mma
+    yield ops.set_dense_arithmetic
+    ops._default_dense_mma = prev
+
+
+# BASELINE config 2 names bf16: the dense layers then run on the bf16 matrix cores too (gemm_bf16.hip: resident-row forward /
+# dX GEMM, split-row weight-gradient GEMM).  bf16x3 (hi/lo split operands) is held to 1e-4 against float64 -- well inside the
+# fp32 gates it has to keep for the whole model; plain bf16 (one rounding per operand, 2^-9) is characterised at 3e-2.
+@pytest.mark.parametrize("mma,tol", [("bf16x3", 1e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("M,K,N", [(300, 258, 1032), (257, 1032, 258), (64, 3, 8), (1000, 402, 1), (33, 66, 64), (5, 272, 68),
+                                   (4099, 256, 256), (200, 1608, 402), (17, 40, 36)])
+@pytest.mark.parametrize("gelu", [False, True])
+def test_linear_forward_backward_on_bf16_matrix_cores(lib, dense_arithmetic, mma, tol, M, K, N, gelu):
+    from news_recommendation_model_amd import ops
+    dense_arithmetic(mma)
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + K + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / np.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.1
+    gy = torch.randn(M, N, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    y_ref = torch.nn.functional.linear(xr, wr, br)
+    if gelu:
+        y_ref = torch.nn.functional.gelu(y_ref)
+    y_ref.backward(gy.double())
+    xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    y = ops.linear(xg, wg, bg, gelu=gelu)
+    y.backward(gy.cuda())
+    assert rel_err(y.detach().cpu().numpy(), y_ref.detach().numpy()) < tol
+    assert rel_err(xg.grad.cpu().numpy(), xr.grad.numpy()) < tol
+    assert rel_err(wg.grad.cpu().numpy(), wr.grad.numpy()) < tol
+    # column sums stay fp32: exact without the activation; with GELU they sum dy * gelu'(z) of the bf16-rounded z
+    assert rel_err(bg.grad.cpu().numpy(), br.grad.numpy()) < (tol if gelu else 1e-5)
+    # and it is a different arithmetic from the fp32 path
+    dense_arithmetic("f32")
+    y32 = ops.linear(xg.detach(), wg.detach(), bg.detach(), gelu=gelu)
+    if K >= 32 and N > 1:
+        assert float((y32 - y.detach()).abs().max()) > 0
+
+
+@pytest.mark.parametrize("M,K,Hd,N", [(300, 1032, 258, 1032), (257, 1032, 258, 1), (64, 264, 66, 264), (33, 72, 18, 5), (7, 16, 4, 3)])
+def test_mlp_and_gate_block_on_bf16x3_matrix_cores(lib, dense_arithmetic, M, K, Hd, N):
+    """fc2(gelu(fc1 x)) [* mul] with every GEMM (forward, dX with the fused GELU', dW) in bf16x3: all epilogues of gemm_nt_rx."""
+    from news_recommendation_model_amd import ops
+    dense_arithmetic("bf16x3")
+    g = torch.Generator(device="cpu").manual_seed(M + 3 * K + 5 * Hd + 7 * N)
+    x = torch.randn(M, K, generator=g)
+    w1 = torch.randn(Hd, K, generator=g) / np.sqrt(K)
+    b1 = torch.randn(Hd, generator=g) * 0.1
+    w2 = torch.randn(N, Hd, generator=g) / np.sqrt(Hd)
+    b2 = torch.randn(N, generator=g) * 0.1
+    mul = torch.randn(M, N, generator=g)
+    gy = torch.randn(M, N, generator=g)
+    F = torch.nn.functional
+    for with_mul in (False, True):
+        if with_mul and N % 4:
+            continue
+        ref = [t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2, mul)]
+        y_ref = F.linear(F.gelu(F.linear(ref[0], ref[1], ref[2])), ref[3], ref[4])
+        if with_mul:
+            y_ref = y_ref * ref[5]
+        y_ref.backward(gy.double())
+        dev = [t.cuda().requires_grad_(True) for t in (x, w1, b1, w2, b2, mul)]
+        y = ops.mlp_gelu(*dev[:5], mul=dev[5] if with_mul else None)
+        y.backward(gy.cuda())
+        assert rel_err(y.detach().cpu().numpy(), y_ref.detach().numpy()) < 1e-4
+        names = ("x", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias") + (("mul",) if with_mul else ())
+        for a, r, name in zip(dev, ref, names):
+            assert rel_err(a.grad.cpu().numpy(), r.grad.numpy()) < 1e-4, (name, with_mul)

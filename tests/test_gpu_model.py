@@ -366,12 +366,23 @@ def test_loss_user_ids_negative_wrap_and_out_of_range_flag(lib):
 
 
 @pytest.mark.parametrize("name", ["c2_small", "tiny_train", "odd_shape", "c3_large", "refdefault"])
-@pytest.mark.parametrize("mma", ["bf16x3", "bf16"])
-def test_bf16_attention_train_step_matches_reference_fixture(lib, mma, name):
-    """BASELINE config 2 arithmetic (bf16 matrix cores in both attentions, fp32 everywhere else) on whole-model
-    fixtures produced by the fp32 REFERENCE.  bf16x3 (hi/lo split operands) is held to the gates of the fp32 path --
-    forward <= 1e-3, gradients <= 1e-2 (measured: 1e-6 / the oracle's own noise floor).  Plain bf16 operands are
-    characterised, not gated: measured logits 4e-4 .. 8e-4, gradients up to 1.2e-2 (c3_large, a fc2 bias); bounds 2e-3 / 3e-2."""
+@pytest.mark.parametrize("mma,dense", [("bf16x3", "f32"), ("bf16", "f32"), ("bf16x3", "bf16x3")])
+def test_bf16_attention_train_step_matches_reference_fixture(lib, mma, dense, name):
+    """BASELINE config 2 arithmetic (bf16 matrix cores in both attentions; dense = f32: fp32 everywhere else, dense = bf16x3:
+    every dense GEMM on the bf16 matrix cores too, as bench.py runs config 2) on whole-model fixtures produced by the fp32
+    REFERENCE.  bf16x3 (hi/lo split operands) is held to the gates of the fp32 path -- forward <= 1e-3, gradients <= 1e-2
+    (measured: 1e-6 / the oracle's own noise floor).  Plain bf16 operands are characterised, not gated: measured logits
+    4e-4 .. 8e-4, gradients up to 1.2e-2 (c3_large, a fc2 bias); bounds 2e-3 / 3e-2."""
+    from news_recommendation_model_amd import ops, trainer
+    prev_dense = ops._default_dense_mma
+    ops.set_dense_arithmetic(dense)
+    try:
+        _bf16_train_step_check(mma, name)
+    finally:
+        ops._default_dense_mma = prev_dense
+
+
+def _bf16_train_step_check(mma, name):
     from news_recommendation_model_amd import trainer
     case, dims, batch, sd, fx = load_case(name)
     model = trainer.build_model(dims, int(batch["user_num"]), sd, device="cuda", attention_mma=mma).train()
