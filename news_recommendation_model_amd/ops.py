@@ -1107,21 +1107,26 @@ def branch_stream(like):
 
 
 def index_error_flag(device):
-    """Device int32 set to 1 by the front-end / loss kernels when a packed row holds an out-of-range table index or a
-    user id outside delta (the reference raises IndexError there; the kernels clamp, flag and go on).  Reading it
-    synchronises, so it is checked by ``check_index_errors`` on request, not on every step."""
+    """int32 flag set to 1 by the front-end / loss kernels when a packed row holds an out-of-range table index or a user id
+    outside delta (the reference raises IndexError there; the kernels clamp, flag and go on).  It lives in PINNED HOST memory
+    that the device writes directly (zero-copy; written only in the error case), so the host can look at it at any time without
+    a copy or a synchronisation: ``trainer.IndexErrorWatch`` does at the start of every step, ``check_index_errors``
+    synchronises first and is therefore exact.  One flag per device."""
     device = torch.device(device)
     if device.index is None:
         device = torch.device(device.type, torch.cuda.current_device())
     key = str(device)
     if key not in _index_error_flag:
-        _index_error_flag[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        _index_error_flag[key] = torch.zeros(1, dtype=torch.int32).pin_memory()
     return _index_error_flag[key]
 
 
 def check_index_errors(device="cuda"):
+    """Wait for the device, then turn a raised flag into the reference's IndexError (and clear it)."""
+    device = torch.device(device)
     flag = index_error_flag(device)
-    if int(flag.item()):
+    torch.cuda.synchronize(device if device.index is not None else None)
+    if int(flag[0]):
         flag.zero_()
         raise IndexError("index out of range (a category / type / time table index of a packed feature row, or a user id "
                          "outside delta)")

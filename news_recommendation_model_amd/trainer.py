@@ -202,40 +202,34 @@ class FlatGradReducer:
 
 
 class IndexErrorWatch:
-    """Out-of-range ids without a host sync.  The kernels clamp a bad table index / user id and set a device flag (the reference
-    raises IndexError at the offending batch: F.embedding at models/user_invariant_interest_model.py:59, delta[id] at
-    models/user_model.py:40).  ``after_step()`` copies the flag to pinned host memory asynchronously; ``before_step()`` looks at
-    the copies that have landed -- and waits for a copy that is more than ``max_lag`` steps old -- and raises: the error
-    surfaces one step after the offending batch when the device keeps up with the host, ``max_lag`` + 1 steps after it at the
-    latest, instead of at the epoch's end."""
+    """Out-of-range ids without a host sync.  The kernels clamp a bad table index / user id and set a flag (the reference raises
+    IndexError at the offending batch: F.embedding at models/user_invariant_interest_model.py:59, delta[id] at
+    models/user_model.py:40).  The flag lives in pinned host memory the device writes directly (ops.index_error_flag), so
+    ``before_step()`` just reads it: the error surfaces at the start of the step after the offending batch when the device keeps
+    up with the host, and ``max_lag`` + 1 steps after it at the latest (``after_step()`` records an event per step and
+    ``before_step()`` waits for the one that is ``max_lag`` steps old) -- not at the epoch's end, and at no cost per step beyond
+    one event record."""
 
     def __init__(self, device, max_lag=2):
         from . import ops
         self.flag = ops.index_error_flag(device)
-        self.device = self.flag.device
+        self.device = torch.device(device)
         self.max_lag = max_lag
-        self.pending = []                                   # (pinned host int32[1], event), oldest first
+        self.pending = []                                   # one event per enqueued step, oldest first
 
     def after_step(self):
-        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
-        host.copy_(self.flag, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
-        self.pending.append((host, ev))
+        self.pending.append(ev)
 
     def before_step(self):
-        while self.pending:
-            host, ev = self.pending[0]
-            if not ev.query():
-                if len(self.pending) <= self.max_lag:
-                    return
-                ev.synchronize()
-            self.pending.pop(0)
-            if int(host[0]):
-                self.pending.clear()
-                self.flag.zero_()
-                raise IndexError("index out of range (a category / type / time table index of a packed feature row, or a user "
-                                 "id outside delta) in a batch of one of the last steps")
+        while self.pending and (len(self.pending) > self.max_lag or self.pending[0].query()):
+            self.pending.pop(0).synchronize()
+        if int(self.flag[0]):
+            self.pending.clear()
+            self.flag.zero_()
+            raise IndexError("index out of range (a category / type / time table index of a packed feature row, or a user "
+                             "id outside delta) in a batch of one of the last steps")
 
 
 _watches = {}

@@ -340,3 +340,62 @@ def test_interleaved_group_walk_matches_oracle(lib, monkeypatch, mma, B, T, H, D
     # the two walks differ only in the order in which float atomics and slab sums meet
     for k in out["0"]:
         assert rel_err(out["1"][k], out["0"][k]) < 1e-4, k
+
+
+def test_full_size_c5_properties(lib):
+    """BASELINE config 5 at FULL size (B=256, H=128, T=64, D=768; z = 6.4 GB): the launch geometry the fuzz lists never reach --
+    three N-chunks of 16 column tiles in the forward, 32-column dz slabs, 4x4 E tiles with the INTERLEAVED group walk of the
+    dt/dW pass (groups of 393 KB) and a grid that exceeds one XCD's L2.  Too big for the CPU oracle as a whole, so: rows are
+    independent of the rest of the launch, the backward is linear in the upstream gradient, weight gradients add over halves of
+    the batch, and one impression matches the oracle (forward and every gradient)."""
+    from news_recommendation_model_amd import ops
+    torch.manual_seed(5)
+    B, T, H, D = 256, 64, 128, 768
+    k1, k2 = 1 / np.sqrt(4 * D), 1 / np.sqrt(D)
+    w1 = (torch.rand(D, 4 * D, device="cuda") * 2 - 1) * k1
+    b1 = (torch.rand(D, device="cuda") * 2 - 1) * k1
+    w2 = (torch.rand(1, D, device="cuda") * 2 - 1) * k2
+    b2 = (torch.rand(1, device="cuda") * 2 - 1) * k2
+    t = torch.randn(B, T, D, device="cuda")
+    h = torch.randn(B, H, D, device="cuda")
+    g = torch.randn(B, T, H, device="cuda")
+    with torch.no_grad():
+        whole = ops.pointwise_attention_scores(t, h, w1, b1, w2, b2)
+        lo = ops.pointwise_attention_scores(t[:100], h[:100], w1, b1, w2, b2)
+        hi = ops.pointwise_attention_scores(t[100:], h[100:], w1, b1, w2, b2)
+    assert torch.equal(whole[:100], lo) and torch.equal(whole[100:], hi)
+    # backward of the full launch: linear in the upstream gradient
+    tq, hq = t.clone().requires_grad_(True), h.clone().requires_grad_(True)
+    wq = [x.clone().requires_grad_(True) for x in (w1, b1, w2, b2)]
+    s = ops.pointwise_attention_scores(tq, hq, *wq)
+    assert torch.allclose(s.detach(), whole, rtol=1e-5, atol=1e-6)            # with / without the z store
+    grads1 = torch.autograd.grad(s, [tq, hq] + wq, g)
+    s = ops.pointwise_attention_scores(tq, hq, *wq)
+    grads2 = torch.autograd.grad(s, [tq, hq] + wq, -0.5 * g)
+    for a, b_ in zip(grads1, grads2):
+        assert rel_err((b_ * -2.0).cpu().numpy().reshape(-1), a.cpu().numpy().reshape(-1)) < 1e-4
+    # weight gradients add over the two halves of the batch; row gradients of a half equal those of the full launch
+    half = B // 2
+    parts = []
+    for sl in (slice(0, half), slice(half, B)):
+        tp, hp = t[sl].clone().requires_grad_(True), h[sl].clone().requires_grad_(True)
+        parts.append(torch.autograd.grad(ops.pointwise_attention_scores(tp, hp, *wq), [tp, hp] + wq, g[sl]))
+    for i in range(2, 6):
+        assert rel_err(grads1[i].cpu().numpy().reshape(-1), (parts[0][i] + parts[1][i]).cpu().numpy().reshape(-1)) < 1e-4
+    assert rel_err(grads1[0][:half].cpu().numpy(), parts[0][0].cpu().numpy()) < 1e-4
+    assert rel_err(grads1[1][half:].cpu().numpy(), parts[1][1].cpu().numpy()) < 1e-4
+    del parts, grads2
+    # one impression against the oracle: scores, target / history gradients (of the FULL launch) and the weight gradients of a
+    # launch over that impression alone
+    i = 77
+    p = {"a.mlp.fc1.weight": w1.cpu(), "a.mlp.fc1.bias": b1.cpu(), "a.mlp.fc2.weight": w2.cpu(), "a.mlp.fc2.bias": b2.cpu()}
+    pc = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    t_c, h_c = t[i:i + 1].cpu().clone().requires_grad_(True), h[i:i + 1].cpu().clone().requires_grad_(True)
+    s_c = orc.pointwise_attention_scores(pc, "a", t_c, h_c)[..., 0]
+    (s_c * g[i:i + 1].cpu()).sum().backward()
+    assert rel_err(whole[i:i + 1].cpu().numpy(), s_c.detach().numpy()) < FWD_TOL
+    assert rel_err(grads1[0][i:i + 1].cpu().numpy(), t_c.grad.numpy()) < GRAD_TOL
+    assert rel_err(grads1[1][i:i + 1].cpu().numpy(), h_c.grad.numpy()) < GRAD_TOL
+    gw_one = torch.autograd.grad(ops.pointwise_attention_scores(t[i:i + 1], h[i:i + 1], *wq), wq, g[i:i + 1])
+    for a, k in zip(gw_one, ("a.mlp.fc1.weight", "a.mlp.fc1.bias", "a.mlp.fc2.weight", "a.mlp.fc2.bias")):
+        assert rel_err(a.cpu().numpy().reshape(-1), pc[k].grad.numpy().reshape(-1)) < GRAD_TOL, k
