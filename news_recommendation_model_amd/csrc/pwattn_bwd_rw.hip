@@ -341,14 +341,14 @@ static hipError_t launch_brw(BwdRwParams p, const BwdRwPlan& pl, int mma, hipStr
     if (base <= 0) return hipSuccess;
     int wgs = brw_cus() / pl.nks;
     if (wgs < 1) wgs = 1;
-    // the candidate walk is cut into tsplit parts when the tasks would not fill the chip's wave slots three times over (dynamic
-    // balance; every part adds its dh with float atomics), as long as a part keeps >= 8 steps
+    // the candidate walk is cut into tsplit parts when the tasks would not fill the chip's wave slots twice over (every part adds
+    // its dh with float atomics: C2, 2 rounds of tasks: 0.191 ms unsplit, 0.201 ms in two parts), as long as a part keeps >= 8 steps
     int nw = BRW_WAVES;
     if (const char* e = getenv("NRM_BRW_WAVES")) { nw = atoi(e); if (nw < 1 || nw > BRW_WAVES) nw = BRW_WAVES; }
     const long slots = (long)wgs * nw;
     int tsplit = 1;
     if (const char* e = getenv("NRM_BRW_TSPLIT")) tsplit = atoi(e);
-    else while (base * tsplit < 3 * slots && p.T / (tsplit + 1) >= 8) ++tsplit;
+    else while (base * tsplit < 2 * slots && p.T / (tsplit + 1) >= 8) ++tsplit;
     if (tsplit < 1) tsplit = 1;
     if (tsplit > p.T) tsplit = p.T;
     p.tsplit = tsplit;
