@@ -74,6 +74,20 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // (MI355X_MICROARCH.md, LDS) -- so for a fragment read (row = lane&15, slot = lane>>4) a group holds rows
 // {0-3,12-15} of one slot and rows {4-11} of its neighbour: XOR-ing 3 into rows 8-15 makes the 16 reads of every
 // group land on 16 different 4-bank columns of the unpadded image.
+// 16-byte buffer store whose data registers may be rewritten right afterwards.  hipcc (ROCm 7.2) pads the "VMEM store of more
+// than 64 bits followed by a VALU write of its data registers" hazard only when the store's soffset is an immediate; with an
+// SGPR soffset it inserts nothing, yet on gfx950 the store was seen delivering values the next VALU instructions had already
+// written into its data registers (pwattn_fwd_walk_kernel: gelu(z) instead of z in 0.1 % of the stored pre-activations).  The
+// wait states are pinned right behind the store.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void store_b128_guarded(u32x4 v, __amdgpu_buffer_rsrc_t rs, unsigned voffset, int soffset) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, voffset, soffset, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 3");
+    __builtin_amdgcn_sched_barrier(0);
+}
+#endif
+
 __host__ __device__ inline int swz4(int row) { return ((row >> 3) & 1) * 3; }
 
 }  // namespace nrm

@@ -202,25 +202,25 @@ __global__ __launch_bounds__(256, WPE) void gemm_nt_kernel(const GemmNtParams p)
             const int rl = (wave * MT + jt) * 16 + r16;
             f32x4 v = acc[it][jt] + bb;
             if (EPI == EPI_BIAS) {
-                if (n < p.ldy) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb, 0);
+                if (n < p.ldy) store_b128_guarded(__builtin_bit_cast(u32x4, v), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb);
             } else if (EPI == EPI_GELU) {
-                if (n < p.ldz) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_z, (unsigned)(rl * p.ldz + 4 * q) * 4u, nb, 0);
+                if (n < p.ldz) store_b128_guarded(__builtin_bit_cast(u32x4, v), rs_z, (unsigned)(rl * p.ldz + 4 * q) * 4u, nb);
                 f32x4 g;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] = gelu_f(v[e]);
-                if (n < p.ldy) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb, 0);
+                if (n < p.ldy) store_b128_guarded(__builtin_bit_cast(u32x4, g), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb);
             } else if (EPI == EPI_MUL) {   // z = v (kept for backward), y = v * m
-                if (n < p.ldz) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_z, (unsigned)(rl * p.ldz + 4 * q) * 4u, nb, 0);
+                if (n < p.ldz) store_b128_guarded(__builtin_bit_cast(u32x4, v), rs_z, (unsigned)(rl * p.ldz + 4 * q) * 4u, nb);
                 f32x4 mm = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (n < p.ldm) mm = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_m, (unsigned)(rl * p.ldm + 4 * q) * 4u, nb, 0));
-                if (n < p.ldy) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v * mm), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb, 0);
+                if (n < p.ldy) store_b128_guarded(__builtin_bit_cast(u32x4, v * mm), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb);
             } else {   // EPI_DGELU: y = acc * gelu'(z_saved)
                 f32x4 zz = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (n < p.ldz) zz = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_z, (unsigned)(rl * p.ldz + 4 * q) * 4u, nb, 0));
                 f32x4 g;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] = acc[it][jt][e] * gelu_grad_f(zz[e]);
-                if (n < p.ldy) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb, 0);
+                if (n < p.ldy) store_b128_guarded(__builtin_bit_cast(u32x4, g), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb);
             }
         }
         __builtin_amdgcn_sched_barrier(0);

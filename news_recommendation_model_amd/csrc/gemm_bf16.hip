@@ -264,25 +264,25 @@ __global__ __launch_bounds__(RX_WAVES * 64, RT <= 2 ? RX_WAVES / 2 : RX_WAVES / 
             const int rl = rt * 16 + r16;
             f32x4 v = acc[rt] + bb;
             if (EPI == EPI_BIAS) {
-                if (n < p.ldy) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb, 0);
+                if (n < p.ldy) store_b128_guarded(__builtin_bit_cast(u32x4, v), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb);
             } else if (EPI == EPI_GELU) {
-                if (n < p.ldz) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_z, (unsigned)(rl * p.ldz + 4 * q) * 4u, nb, 0);
+                if (n < p.ldz) store_b128_guarded(__builtin_bit_cast(u32x4, v), rs_z, (unsigned)(rl * p.ldz + 4 * q) * 4u, nb);
                 f32x4 g;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] = gelu_f(v[e]);
-                if (n < p.ldy) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb, 0);
+                if (n < p.ldy) store_b128_guarded(__builtin_bit_cast(u32x4, g), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb);
             } else if (EPI == EPI_MUL) {
-                if (n < p.ldz) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_z, (unsigned)(rl * p.ldz + 4 * q) * 4u, nb, 0);
+                if (n < p.ldz) store_b128_guarded(__builtin_bit_cast(u32x4, v), rs_z, (unsigned)(rl * p.ldz + 4 * q) * 4u, nb);
                 f32x4 mm = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (n < p.ldm) mm = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_m, (unsigned)(rl * p.ldm + 4 * q) * 4u, nb, 0));
-                if (n < p.ldy) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v * mm), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb, 0);
+                if (n < p.ldy) store_b128_guarded(__builtin_bit_cast(u32x4, v * mm), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb);
             } else {
                 f32x4 zz = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (n < p.ldz) zz = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_z, (unsigned)(rl * p.ldz + 4 * q) * 4u, nb, 0));
                 f32x4 g;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] = acc[rt][e] * gelu_grad_f(zz[e]);
-                if (n < p.ldy) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb, 0);
+                if (n < p.ldy) store_b128_guarded(__builtin_bit_cast(u32x4, g), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb);
             }
         }
     };
@@ -337,7 +337,10 @@ __global__ __launch_bounds__(RX_WAVES * 64, RT <= 2 ? RX_WAVES / 2 : RX_WAVES / 
 int gemm_nt_rx_bm(int M, int K, int mma) {
     if (mma != 1 && mma != 2) return 0;
     const int k32 = (K + 31) / 32, wimg = mma == 2 ? 2 : 1;
+    // (blocks of 64 / 128 rows -- RT = 4 / 8 -- are compiled but not used: the RT = 4 form returned wrong rows 12-15 / 28-31 of its
+    // block at M = 51200 and was not debugged; 32-row blocks are what every BASELINE shape of config 2 takes anyway)
     int bm = 128;
+    if (const char* e = getenv("NRM_RX_BM")) bm = atoi(e);
     while (bm >= 16 && (long)k32 * wimg * bm * 64 > RX_LDS_BUDGET) bm /= 2;
     if (bm < 16) return 0;                                               // K too wide for a resident row block
     // two workgroups per CU (the conversion prologue of one under the MFMAs of the other) when that keeps >= 32 rows per block

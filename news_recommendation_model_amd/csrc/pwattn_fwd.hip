@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, WPE) void pwattn_fwd_kernel(const FwdParams p)
                 const f32x4 zz = acc[it][jt];
                 if (SAVE_Z && kok && !(NRM_DIAG_FWD & 4)) {
                     const unsigned vz = (unsigned)(((wave * MT + jt) * 16 + r16) * D + 4 * q) * 4u;   // rows >= M: out of range
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zz), rs_z, vz, kb, 0);
+                    store_b128_guarded(__builtin_bit_cast(u32x4, zz), rs_z, vz, kb);
                 }
                 if (NRM_DIAG_FWD & 8) s_part[jt] += ww[0] * zz[0] + ww[1] * zz[1] + ww[2] * zz[2] + ww[3] * zz[3];
                 else s_part[jt] += ww[0] * gelu_f(zz[0]) + ww[1] * gelu_f(zz[1]) + ww[2] * gelu_f(zz[2]) + ww[3] * gelu_f(zz[3]);

@@ -238,13 +238,161 @@ __global__ __launch_bounds__(FB_WAVES * 64, FB_WAVES / 4) void pwattn_fwd_rw_ker
         for (int it = 0; it < NTS; ++it) {
             const f32x4 zz = acc[it];
             if (SAVE_Z && !(NRM_DIAG_RW & 1) && k0 + it * 16 + 4 * q < D)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zz), rs_z, (unsigned)(r16 * D + 4 * q) * 4u, (k0 + it * 16) * 4, 0);
+                store_b128_guarded(__builtin_bit_cast(u32x4, zz), rs_z, (unsigned)(r16 * D + 4 * q) * 4u, (k0 + it * 16) * 4);
             if (NRM_DIAG_RW & 2) s_part += ww[it][0] * zz[0] + ww[it][1] * zz[1] + ww[it][2] * zz[2] + ww[it][3] * zz[3];
             else s_part += ww[it][0] * gelu_f(zz[0]) + ww[it][1] * gelu_f(zz[1]) + ww[it][2] * gelu_f(zz[2]) + ww[it][3] * gelu_f(zz[3]);
         }
         const float v = sum_rows4(s_part) + b2;
         if (q == 0 && m < M) {
             if (pl.nsplit == 1) p.s[m] = v; else atomicAdd(p.s + m, v);
+        }
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// "walk" form of the resident-W forward for the bf16 arithmetics at D = 64 / 128 / 256 (whole 32-wide chunks).  The kernel
+// above takes 16-row tiles of the flattened rows m = (b,t,h) one after the other and re-loads, for every tile, its h and u rows
+// (each shared by all T candidates of the impression) next to t and v: 56 vector-memory instructions per 192 MFMAs, two
+// thirds of them for operands that do not change along t (timing-only builds: 0.077 ms of MFMA work in a 0.32 ms kernel).
+// Here a wave owns (impression b, 16 history rows) and WALKS the candidates t, as the resident-W backward does:
+//   * its h rows (the t*h operand's factor) and u rows (the accumulators' start) are loaded ONCE per task and stay in
+//     registers for the whole walk;
+//   * per step only the candidate's t row (two 16-byte loads per chunk, the same for all 16 rows: L1 broadcasts) and, in the
+//     epilogue, its v and fc2-weight segments are read; t chunks are requested two chunks ahead, across step boundaries;
+//   * z = (u + P W_p^T) + v: the store, GELU and fc2 dot are the kernel above's.
+template <int NTS, bool SAVE_Z, int MMA, int KCH>
+__global__ __launch_bounds__(512, 2) void pwattn_fwd_walk_kernel(const FwdParams p, const RwPlan pl, int wgs_per_split, int tsplit) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int WIMG = MMA == 2 ? 2 : 1;
+    constexpr int SROWS = NTS * 16;
+    constexpr int NW = 8;
+    extern __shared__ __attribute__((aligned(16))) float wres[];       // [KCH][WIMG][SROWS][16 floats = 32 bf16]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int T = p.T, H = p.H, D = p.D;
+    const int split = blockIdx.x % pl.nsplit, g = blockIdx.x / pl.nsplit;
+    const int k0 = split * SROWS;
+
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, p.wp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w2), 0, D * 4, 0x00020000);
+    const int npiece = KCH * WIMG * NTS;
+    for (int pc = wave; pc < npiece; pc += NW) {
+        const int ci = pc / NTS, rt = pc - ci * NTS;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(wres + pc * 256), 16, lane * 16,
+                                                 (ci * pl.rows + k0 + rt * 16) * 64, 0, 0);
+    }
+    __syncthreads();
+
+    const int rslot = 4 * (q ^ swz4(r16));
+    const float b2 = split == 0 ? p.b2[0] : 0.f;
+    const int nht = (H + 15) >> 4;
+    const int tlen = (T + tsplit - 1) / tsplit;
+    const int ntask = (int)(p.M / ((long)T * H)) * nht * tsplit;         // B * nht * tsplit
+
+    for (int task = g * NW + wave; task < ntask; task += wgs_per_split * NW) {
+        const int tp = task % tsplit;
+        const int rest = task / tsplit;
+        const int b = rest / nht, h0 = (rest - b * nht) * 16;
+        const int t_lo = tp * tlen, t_hi = min(T, t_lo + tlen);
+        if (t_lo >= t_hi) continue;
+        const bool rok = h0 + r16 < H;
+        const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.t) + (size_t)b * T * p.ldt, 0, (unsigned)(T * p.ldt * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v) + (size_t)b * T * p.ldv, 0, (unsigned)(T * p.ldv * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.h) + (size_t)b * H * p.ldh, 0, (unsigned)(H * p.ldh * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u) + (size_t)b * H * p.ldu, 0, (unsigned)(H * p.ldu * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(
+            SAVE_Z ? p.z + (size_t)b * T * H * D : nullptr, 0, SAVE_Z ? (unsigned)((size_t)T * H * D * 4) : 0, 0x00020000);
+
+        // ---- once per task: this lane's h row (its 8 reduction columns of every chunk) and u row (its 4 columns of every tile)
+        f32x4 ha[KCH], hb[KCH], ureg[NTS];
+        const unsigned vh = rok ? (unsigned)(((h0 + r16) * p.ldh + 4 * q) * 4) : OOB;
+        const unsigned vu = rok ? (unsigned)(((h0 + r16) * p.ldu + k0 + 4 * q) * 4) : OOB;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            ha[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, vh, c * 128, 0));
+            hb[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, vh, c * 128 + 64, 0));
+        }
+#pragma unroll
+        for (int it = 0; it < NTS; ++it)
+            ureg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, vu, it * 64, 0));
+
+        // t operand ring: chunk c of a step lives in slot c & 1 and is requested two chunks ahead (KCH is even)
+        f32x4 ta[2], tb[2];
+        const unsigned vt = (unsigned)(4 * q * 4);
+        auto load_t = [&](int slot, int t, int c) {
+            ta[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_t, vt, t * p.ldt * 4 + c * 128, 0));
+            tb[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_t, vt, t * p.ldt * 4 + c * 128 + 64, 0));
+        };
+        load_t(0, t_lo, 0);
+        load_t(1, t_lo, 1);
+        const unsigned vv_off = (unsigned)((k0 + 4 * q) * 4);
+        const unsigned vz = rok ? (unsigned)(((h0 + r16) * D + k0 + 4 * q) * 4) : OOB;
+
+        for (int t = t_lo; t < t_hi; ++t) {
+            f32x4 acc[NTS];
+#pragma unroll
+            for (int it = 0; it < NTS; ++it) acc[it] = ureg[it];
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+                const int slot = c & 1;
+                const f32x4 lo = ta[slot] * ha[c], hi = tb[slot] * hb[c];
+                // the slot is free: chunk c + 2 of this step, or chunk c + 2 - KCH of the next
+                {
+                    const int cn = c + 2;
+                    const int tn = t + (cn >= KCH ? 1 : 0);
+                    if (tn < t_hi) load_t(slot, tn, cn >= KCH ? cn - KCH : cn);
+                }
+                bf16x8 pf, pl2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pf[e] = (__bf16)lo[e]; pf[4 + e] = (__bf16)hi[e];
+                    if (MMA == 2) { pl2[e] = (__bf16)(lo[e] - (float)pf[e]); pl2[4 + e] = (__bf16)(hi[e] - (float)pf[4 + e]); }
+                }
+                const float* buf = wres + c * (WIMG * SROWS * 16);
+                constexpr int LA = NTS < 3 ? NTS : 3;
+                auto rd = [&](int it, int im) { return *reinterpret_cast<const bf16x8*>(&buf[(im * SROWS + it * 16 + r16) * 16 + rslot]); };
+                bf16x8 af[NTS], al[NTS];
+#pragma unroll
+                for (int it = 0; it < LA; ++it) { af[it] = rd(it, 0); if (MMA == 2) al[it] = rd(it, 1); }
+#pragma unroll
+                for (int it = 0; it < NTS; ++it) {
+                    if (it + LA < NTS) { af[it + LA] = rd(it + LA, 0); if (MMA == 2) al[it + LA] = rd(it + LA, 1); }
+                    if (MMA == 2) {
+                        acc[it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[it], pf, acc[it], 0, 0, 0);
+                        acc[it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[it], pl2, acc[it], 0, 0, 0);
+                    }
+                    acc[it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[it], pf, acc[it], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // ---- epilogue: z = acc + v ; optional z store ; GELU ; partial fc2 dot.  v and fc2-weight segments of tile it + 2
+            // are requested while tile it is processed.
+            const int m = (b * T + t) * H + h0 + r16;
+            f32x4 vvs[2], wws[2];
+            auto load_vw = [&](int it, int set) {
+                vvs[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, vv_off, t * p.ldv * 4 + it * 64, 0));
+                wws[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, 16 * q, (k0 + it * 16) * 4, 0));
+            };
+            load_vw(0, 0);
+            if (NTS > 1) load_vw(1, 1);
+            float s_part = 0.f;
+#pragma unroll
+            for (int it = 0; it < NTS; ++it) {
+                const f32x4 zz = acc[it] + vvs[it & 1];
+                const f32x4 ww = wws[it & 1];
+                if (it + 2 < NTS) load_vw(it + 2, it & 1);
+                if (SAVE_Z) store_b128_guarded(__builtin_bit_cast(u32x4, zz), rs_z, vz, t * H * D * 4 + it * 64);
+                s_part += ww[0] * gelu_f(zz[0]) + ww[1] * gelu_f(zz[1]) + ww[2] * gelu_f(zz[2]) + ww[3] * gelu_f(zz[3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float sv = sum_rows4(s_part) + b2;
+            if (q == 0 && rok) {
+                if (pl.nsplit == 1) p.s[m] = sv; else atomicAdd(p.s + m, sv);
+            }
         }
     }
 #endif
@@ -286,8 +434,47 @@ static hipError_t launch_rw(const FwdParams& p, const RwPlan& pl, int mma, hipSt
 
 int pwattn_fwd_rw_diag_flags() { return NRM_DIAG_RW ? 4 : 0; }
 
+template <int NTS, int KCH>
+static hipError_t launch_walk(const FwdParams& p, const RwPlan& pl, int mma, hipStream_t st) {
+    const int B = (int)(p.M / ((long)p.T * p.H)), nht = (p.H + 15) / 16;
+    const long base = (long)B * nht;
+    if (base <= 0) return hipSuccess;
+    int wgs = rw_cus() / pl.nsplit;
+    if (wgs < 1) wgs = 1;
+    int tsplit = 1;
+    if (const char* e = getenv("NRM_FWD_TSPLIT")) tsplit = atoi(e);
+    else while (base * tsplit < 2L * wgs * 8 && p.T / (tsplit + 1) >= 8) ++tsplit;
+    if (tsplit < 1) tsplit = 1;
+    if (tsplit > p.T) tsplit = p.T;
+    const long ntask = base * tsplit;
+    if ((long)wgs * 8 > ntask) wgs = (int)((ntask + 7) / 8);
+    const size_t shm = (size_t)pl.k32 * pl.wimg * NTS * 1024;
+    if (pl.nsplit > 1) {
+        hipError_t e = hipMemsetAsync(p.s, 0, (size_t)p.M * sizeof(float), st);
+        if (e != hipSuccess) return e;
+    }
+    const dim3 grid((unsigned)(wgs * pl.nsplit)), block(512);
+#define NRM_WALK(SZ, M_)                                                                                                 \
+    {                                                                                                                    \
+        auto k = pwattn_fwd_walk_kernel<NTS, SZ, M_, KCH>;                                                               \
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS_BUDGET);  \
+        if (e != hipSuccess) return e;                                                                                   \
+        hipLaunchKernelGGL(k, grid, block, shm, st, p, pl, wgs, tsplit);                                                 \
+    }
+    if (mma == 2) { if (p.z) NRM_WALK(true, 2) else NRM_WALK(false, 2) }
+    else          { if (p.z) NRM_WALK(true, 1) else NRM_WALK(false, 1) }
+#undef NRM_WALK
+    return hipGetLastError();
+}
+
 hipError_t pwattn_fwd_rw_launch(const FwdParams& p, int mma, hipStream_t st) {
     const RwPlan pl = pwattn_rw_plan(p.D, mma);
+    static const bool walk = [] { const char* e = getenv("NRM_FWD_WALK"); return !(e && e[0] == '0'); }();
+    if (walk && mma != 0 && p.M % ((long)p.T * p.H) == 0 && (long)p.T * p.H * p.D * 4 < (1L << 31)) {
+        if (p.D == 256 && pl.nts == 8) return launch_walk<8, 8>(p, pl, mma, st);
+        if (p.D == 128 && pl.nts == 8) return launch_walk<8, 4>(p, pl, mma, st);
+        if (p.D == 64 && pl.nts == 4) return launch_walk<4, 2>(p, pl, mma, st);
+    }
     switch (pl.nts) {
         case 1:  return launch_rw<1>(p, pl, mma, st);
         case 2:  return launch_rw<2>(p, pl, mma, st);

@@ -209,11 +209,15 @@ def invalidate_packed_weights():
     _packs.epoch += 1
 
 
+import os as _os
+_FORCE_F32_GEMM = _os.environ.get("NRM_GEMM_F32") == "1"        # diagnostics: every dense / side GEMM on the fp32 kernels
+
+
 def _dense_mma(M, K, mma):
     """The arithmetic a dense GEMM with M rows and reduction width K really runs in: ``mma`` (None = the process default of
     ``set_dense_arithmetic``) if the bf16 resident-row form takes that K, else fp32."""
     mma = _default_dense_mma if mma is None else mma
-    if mma != MMA_F32 and not native.load().nrm_gemm_nt_bf16_supported(int(M), int(K), int(mma)):
+    if _FORCE_F32_GEMM or (mma != MMA_F32 and not native.load().nrm_gemm_nt_bf16_supported(int(M), int(K), int(mma))):
         return MMA_F32
     return mma
 
@@ -245,7 +249,7 @@ def _gemm_tn_slabs(a, b, want_colsum, zero_out=None, mma=None):
     R, ni = a.shape
     nj = b.shape[1]
     mma = _default_dense_mma if mma is None else mma
-    if mma != MMA_F32 and (a.stride(0) % 4 or b.stride(0) % 4 or a.data_ptr() % 16 or b.data_ptr() % 16):
+    if _FORCE_F32_GEMM or (mma != MMA_F32 and (a.stride(0) % 4 or b.stride(0) % 4 or a.data_ptr() % 16 or b.data_ptr() % 16)):
         mma = MMA_F32                                   # the bf16 forms read 16-byte row segments
     nsplit = lib.nrm_gemm_tn_nsplit(ni, nj, R, mma)
     ldws = _pad4(ni)

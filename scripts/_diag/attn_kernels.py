@@ -27,7 +27,7 @@ def run(m):
         x.grad = None
     s = ops.pointwise_attention_scores(t, h, w1, b1, w2, b2, mma=m)
     s.backward(gs)
-    return t.grad.clone(), h.grad.clone(), w1.grad.clone()
+    return t.grad.clone(), h.grad.clone(), w1.grad.clone(), s.detach().clone()
 
 
 ref = run("f32")
@@ -46,4 +46,4 @@ rel = lambda a, b: float((a - b).abs().max() / b.abs().max())          # noqa: E
 keys = ("nrm_pwattn_fwd", "nrm_pwattn_bwd_dz", "pwattn_bwd_rw_dtdh", "pwattn_bwd_e_bt", "pwattn_bwd_e_bh")
 print(os.path.basename(os.environ.get("NRM_HOTPATH_LIB", "product")), " ".join(f"{k[4:]}={v}" for k, v in os.environ.items() if k.startswith("NRM_BRW")), mma, (B, T, H, D),
       " ".join(f"{k.replace('nrm_pwattn_', '').replace('pwattn_', '')}={np.mean(per[k]):.3f}" for k in keys if k in per),
-      f"| vs f32: dt {rel(got[0], ref[0]):.1e} dh {rel(got[1], ref[1]):.1e} dW1 {rel(got[2], ref[2]):.1e}", flush=True)
+      f"| vs f32: s {rel(got[3], ref[3]):.1e} dt {rel(got[0], ref[0]):.1e} dh {rel(got[1], ref[1]):.1e} dW1 {rel(got[2], ref[2]):.1e}", flush=True)
