@@ -41,6 +41,7 @@ HBM_PEAK_GBS = 8000.0             # same guide: HBM3E spec peak (6.3 TB/s measur
 PMC_TRAFFIC_FILES = {("C3-large", "f32"): "r3_c3_pmc_traffic.json", ("C5-long", "f32"): "r3_c5_pmc_traffic.json",
                      ("C2-small", "bf16x3"): "r3_c2_bf16x3_pmc_traffic.json", ("C1-demo", "f32"): "r3_c1_pmc_traffic.json",
                      ("ref-default", "f32"): "r3_refdefault_pmc_traffic.json"}
+INFER_TRAFFIC_FILES = {("C3-large", "f32"): "r3_infer_c3_pmc_traffic.json"}
 
 
 def parse():
@@ -347,6 +348,15 @@ def main_infer(args):
     roof = {"bound": "mfma", "kernel": "nrm_pwattn_fwd (no z store)", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(ach / peak, 4), "flops_per_launch": flops, "mean_launch_ms": round(fwd_ms, 4), "traffic": None,
             "traffic_source": "no committed PMC profile for the inference forward"}
+    tpath = os.path.join(ROOT, "profiles", INFER_TRAFFIC_FILES.get((args.workload, args.dtype), ""))
+    if not args.batch and os.path.isfile(tpath):
+        from news_recommendation_model_amd import build as _build
+        prof = json.load(open(tpath))
+        if prof.get("kernel_sources_sha256") != _build.sources_digest():
+            roof["traffic_source"] = f"stale: {os.path.basename(tpath)} was measured on other kernel sources (commit {prof.get('git_head', '?')})"
+        else:
+            roof["traffic"] = prof.get("nrm_pwattn_fwd", {}).get("corrected_bytes")
+            roof["traffic_source"] = f"{os.path.basename(tpath)} (rocprofv3 --pmc, commit {prof.get('git_head', '?')}, same kernel sources)"
     ms = elapsed / args.steps * 1e3
     line = {"metric": "inference impressions/sec (reference test.py:31-74 model_test, one model)", "value": round(B * args.steps / elapsed, 2),
             "unit": "impressions/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": round(ms, 3),

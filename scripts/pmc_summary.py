@@ -34,9 +34,13 @@ trace = newest(f"{src}/stats/*/*_kernel_trace.csv")
 shutil.copy(stats, f"{pre}_bench_kernel_stats.csv")
 # steps in the profiled run = launches of the once-per-step Adam kernel
 steps = sum(1 for r in csv.DictReader(open(trace)) if "adam_dev_kernel" in r["Kernel_Name"])
+unit = "steps"
+if steps == 0:      # --mode infer: no optimizer; one model forward packs W_p once per attention
+    steps = sum(1 for r in csv.DictReader(open(trace)) if "pack_wp" in r["Kernel_Name"]) // 2
+    unit = "model forwards (calls/step below = per forward)"
 summary = subprocess.run([sys.executable, "scripts/rocprof_summary.py", f"{pre}_bench_kernel_stats.csv", str(max(steps, 1))],
                          capture_output=True, text=True, check=True).stdout
-summary = f"# {json.dumps(stamp)}\n# rocprofv3 --kernel-trace --stats of: bench.py (see {pre}_bench.json 'config'), {steps} steps incl. warm-up\n" + summary
+summary = f"# {json.dumps(stamp)}\n# rocprofv3 --kernel-trace --stats of: bench.py (see {pre}_bench.json 'config'), {steps} {unit} incl. warm-up\n" + summary
 open(f"{pre}_bench_kernel_stats.summary.txt", "w").write(summary)
 print(summary)
 
@@ -95,4 +99,4 @@ for t, kn in names.items():
 json.dump(traffic, open(f"{pre}_pmc_traffic.json", "w"), indent=1)
 shutil.copy(f"{src}/bench.json", f"{pre}_bench.json")
 d = json.loads(open(f"{pre}_bench.json").read().strip().splitlines()[-1])
-print(d["value"], d["ms_per_step"], d["roofline"], d.get("cpu_baseline", {}).get("value"), d.get("pcie_inclusive"), d["fwd_auc_parity"])
+print(d["value"], d["ms_per_step"], d["roofline"], d.get("cpu_baseline", {}).get("value"), d.get("pcie_inclusive"), d.get("fwd_auc_parity"))
