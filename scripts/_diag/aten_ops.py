@@ -14,6 +14,10 @@ from news_recommendation_model_amd.config import Dims, WORKLOADS
 wl = WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "C1-demo"]
 dims = Dims.for_emb(wl["emb"])
 B = min(wl["B"], int(sys.argv[2]) if len(sys.argv) > 2 else 64)
+if len(sys.argv) > 3:           # attention + dense arithmetic, e.g. bf16x3
+    from news_recommendation_model_amd import ops
+    ops.set_attention_arithmetic(sys.argv[3])
+    ops.set_dense_arithmetic(sys.argv[3])
 batch = synth.make_batch(dims, B, wl["H"], wl["T"], seed=0, dtype=np.float32)
 sd = synth.make_state_dict(dims, seed=1, user_num=int(batch["user_num"]), perturb=False)
 model = trainer.build_model(dims, int(batch["user_num"]), sd).train()
@@ -25,8 +29,11 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     trainer.train_step(model, opt, tb)
     torch.cuda.synchronize()
-rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and e.device_time_total > 0
-        and e.key in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::add", "aten::fill_", "aten::mul", "aten::sum", "aten::_to_copy")]
+rows = [e for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=12) if e.key.startswith("aten::") and e.self_device_time_total > 0]
 rows.sort(key=lambda e: (e.key, -e.count))
+tot = 0.0
 for e in rows:
-    print(f"{e.count:4d} {e.key:20s} dev_us={e.device_time_total:7.1f}  shapes={e.input_shapes}")
+    where = [f.split("/")[-1] for f in e.stack if "news_recommendation_model_amd" in f or "bench.py" in f][:3]
+    tot += e.self_device_time_total
+    print(f"{e.count:4d} {e.key:22s} self_dev_us={e.self_device_time_total:7.1f}  shapes={e.input_shapes}  <- {' <- '.join(where)}")
+print("ATen self device time per step: %.1f us" % tot)
