@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define NRM_ABI_VERSION 3
+#define NRM_ABI_VERSION 4
 #define NRM_OK 0
 #define NRM_EINVAL (-1)   /* bad shape / alignment / null pointer */
 #define NRM_ELAUNCH (-2)  /* HIP launch error */
@@ -60,14 +60,15 @@ int nrm_pwattn_fwd(const float* t, const float* h, const float* u, const float* 
 /* backward, step 1 (autograd of attention_model.py:29-32 through GELU and fc2), one pass over z:
  *   z <- dz = ds * w2 * gelu'(z) in place;  dw2[k] += sum ds*gelu(z)   (dw2 must be initialised)
  *   du[b,h,:] = sum_t dz[b,t,h,:]  (gradient of u)      dv[b,t,:] = sum_h dz[b,t,h,:]  (gradient of v)
- * ds [B,T,H]; du [B,H,D] and dv [B,T,D] are overwritten (histories longer than 256 rows are processed in chunks). */
+ * ds [B,T,H]; du [B,H,D] and dv [B,T,D] are overwritten (histories longer than 256 rows are processed in chunks).
+ *   db2 (optional, may be NULL): *db2 += sum ds, the fc2 bias gradient (must be initialised like dw2) */
 /* dz_format: how dz is left in z_inout.  NRM_DZ_F32: fp32.  NRM_DZ_HL4 (for the bf16 arithmetics): every aligned group of 4
  * values as 4 bf16 hi + 4 bf16 lo (lo = bf16 of the rounding remainder) in the same 16 bytes -- the MFMA-ready operand that
  * nrm_pwattn_bwd_rw_dtdh and the dW_p-only pass of nrm_pwattn_bwd_contract read without conversion (du, dv, dw2 are computed
  * from the fp32 values either way). */
 #define NRM_DZ_F32 0
 #define NRM_DZ_HL4 1
-int nrm_pwattn_bwd_dz(float* z_inout, const float* ds, const float* w2, float* dw2, float* du, float* dv,
+int nrm_pwattn_bwd_dz(float* z_inout, const float* ds, const float* w2, float* dw2, float* db2, float* du, float* dv,
                       int B, int T, int H, int D, int dz_format, nrm_stream_t stream);
 /* number of [D,D] partial slabs nrm_pwattn_bwd_contract writes into `ws` (depends on the arithmetic: tile shapes differ) */
 int nrm_pwattn_bwd_nsplit(int B, int T, int H, int D, int mma);
@@ -180,12 +181,17 @@ int nrm_concat_cols(const float* const* srcs, const long* lds, const int* widths
                     nrm_stream_t stream);
 
 /* ---- weighted pool (reference models/user_invariant_interest_model.py:86-87, no softmax, no mask)
- * out[b,i,:] (+)= sum_j W[b,i,j] * X[b,j,:]   W element (b,i,j) at W[b*wsb + i*wsi + j*wsj]; X [B,J,D], out [B,I,D]
- * contiguous.  forward: W = scores [B,T,H], X = history;  d history: W = scores^T (wsi=1, wsj=H), X = d pooled */
-int nrm_pool_bmm(const float* W, long wsb, long wsi, long wsj, const float* X, float* out,
+ * out[b,i,:] (+)= sum_j W[b,i,j] * X[b,j,:]   W element (b,i,j) at W[b*wsb + i*wsi + j*wsj]; X [B,J,D] with row stride ldx
+ * (>= D: a column block of a wider matrix, e.g. the head gradient's pooled slice); out [B,I,D] contiguous.
+ * forward: W = scores [B,T,H], X = history;  d history: W = scores^T (wsi=1, wsj=H), X = d pooled, accumulate = 1 adds onto
+ * the history gradient the attention backward has already written */
+int nrm_pool_bmm(const float* W, long wsb, long wsi, long wsj, const float* X, int ldx, float* out,
                  int B, int I, int J, int D, int accumulate, nrm_stream_t stream);
-/* ds[b,t,h] = sum_d g[b,t,d] * h[b,h,d]   (gradient of the pool w.r.t. the scores; wave shuffle reductions) */
-int nrm_pool_rowdot(const float* g, const float* h, float* ds, int B, int T, int H, int D, nrm_stream_t stream);
+/* ds[b,t,h] = sum_d g[b,t,d] * h[b,h,d]   (gradient of the pool w.r.t. the scores); g [B,T,D] with row stride ldg.
+ * zero_out / zero_n (optional): zero_n floats at zero_out are cleared by this launch -- the dw2 | db2 accumulators of the
+ * nrm_pwattn_bwd_dz call that follows on the same stream (one launch less per attention) */
+int nrm_pool_rowdot(const float* g, int ldg, const float* h, float* ds, int B, int T, int H, int D, float* zero_out, int zero_n,
+                    nrm_stream_t stream);
 
 /* ---- loss (reference models/user_model.py:37-43): (1-alpha)*BCE(softmax_T(out), y) + alpha*BCE(softmax_T(out +
  * delta[id]), y), mean over B*T, log clamped at -100.  Writes loss_sum[0] += loss, dout [B,T] = dL/dout and

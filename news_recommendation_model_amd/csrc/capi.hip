@@ -103,13 +103,13 @@ int nrm_pwattn_fwd(const float* t, const float* h, const float* u, const float* 
     return check_hip(nrm::pwattn_fwd_launch(p, pl, mma, (hipStream_t)stream), "pwattn_fwd");
 }
 
-int nrm_pwattn_bwd_dz(float* z_inout, const float* ds, const float* w2, float* dw2, float* du, float* dv,
+int nrm_pwattn_bwd_dz(float* z_inout, const float* ds, const float* w2, float* dw2, float* db2, float* du, float* dv,
                       int B, int T, int H, int D, int dz_format, nrm_stream_t stream) {
     if (int rc = check_dims("nrm_pwattn_bwd_dz", B, T, H, D)) return rc;
     if (!z_inout || !ds || !w2 || !dw2 || !du || !dv) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dz: null pointer");
     if (B > 65535) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dz: B=%d > 65535 (one grid row per impression)", B);
     if (dz_format != NRM_DZ_F32 && dz_format != NRM_DZ_HL4) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dz: dz_format=%d (NRM_DZ_F32 or NRM_DZ_HL4)", dz_format);
-    return check_hip(nrm::bwd_dz_launch(z_inout, ds, w2, dw2, du, dv, B, T, H, D, dz_format, (hipStream_t)stream), "bwd_dz");
+    return check_hip(nrm::bwd_dz_launch(z_inout, ds, w2, dw2, db2, du, dv, B, T, H, D, dz_format, (hipStream_t)stream), "bwd_dz");
 }
 
 int nrm_pwattn_bwd_rw_supported(int D, int mma) { return nrm::pwattn_bwd_rw_plan(D, mma).ng ? 1 : 0; }
@@ -398,18 +398,24 @@ int nrm_concat_cols(const float* const* srcs, const long* lds, const int* widths
 }
 
 // ------------------------------------------------------------------------------------------- pool / loss / Adam
-int nrm_pool_bmm(const float* W, long wsb, long wsi, long wsj, const float* X, float* out,
+int nrm_pool_bmm(const float* W, long wsb, long wsi, long wsj, const float* X, int ldx, float* out,
                  int B, int I, int J, int D, int accumulate, nrm_stream_t stream) {
     if (!W || !X || !out) return fail(NRM_EINVAL, "nrm_pool_bmm: null pointer");
     if (B < 0 || I <= 0 || J <= 0 || D <= 0 || D % 4 || B > 65535) return fail(NRM_EINVAL, "nrm_pool_bmm: B=%d I=%d J=%d D=%d", B, I, J, D);
-    return check_hip(nrm::bmm_rows_launch(W, wsb, wsi, wsj, X, (long)J * D, D, out, (long)I * D, D, B, I, J, D, accumulate,
+    if (ldx < D || ldx % 4 || !al16(X) || (long)J * ldx * 4 >= (1L << 31))
+        return fail(NRM_EINVAL, "nrm_pool_bmm: ldx=%d (>= D, a multiple of 4, X 16-byte aligned, J*ldx*4 < 2^31)", ldx);
+    return check_hip(nrm::bmm_rows_launch(W, wsb, wsi, wsj, X, (long)J * ldx, ldx, out, (long)I * D, D, B, I, J, D, accumulate,
                                           (hipStream_t)stream), "pool_bmm");
 }
 
-int nrm_pool_rowdot(const float* g, const float* h, float* ds, int B, int T, int H, int D, nrm_stream_t stream) {
+int nrm_pool_rowdot(const float* g, int ldg, const float* h, float* ds, int B, int T, int H, int D, float* zero_out, int zero_n,
+                    nrm_stream_t stream) {
     if (!g || !h || !ds) return fail(NRM_EINVAL, "nrm_pool_rowdot: null pointer");
     if (B < 0 || T <= 0 || H <= 0 || D <= 0 || D % 4 || D > 1024 || B > 65535) return fail(NRM_EINVAL, "nrm_pool_rowdot: B=%d T=%d H=%d D=%d", B, T, H, D);
-    return check_hip(nrm::rowdot_launch(g, (long)T * D, D, h, (long)H * D, D, ds, B, T, H, D, (hipStream_t)stream), "pool_rowdot");
+    if (ldg < D || ldg % 4 || !al16(g) || (long)T * ldg * 4 >= (1L << 31))
+        return fail(NRM_EINVAL, "nrm_pool_rowdot: ldg=%d (>= D, a multiple of 4, g 16-byte aligned, T*ldg*4 < 2^31)", ldg);
+    if (zero_n < 0 || (zero_n > 0 && !zero_out)) return fail(NRM_EINVAL, "nrm_pool_rowdot: zero_n=%d without zero_out", zero_n);
+    return check_hip(nrm::rowdot_launch(g, (long)T * ldg, ldg, h, (long)H * D, D, ds, B, T, H, D, zero_out, zero_n, (hipStream_t)stream), "pool_rowdot");
 }
 
 int nrm_loss_fwd_bwd(const float* out, const float* label, const long* user_id, const float* delta, long n_delta, float alpha,

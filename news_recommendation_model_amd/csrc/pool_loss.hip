@@ -85,8 +85,12 @@ __global__ __launch_bounds__(256) void bmm_rows_kernel(const float* __restrict__
 // descriptors.  The chunk after the current one is requested before the current MFMAs.
 __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ g, long gsb, int ldg,
                                                      const float* __restrict__ h, long hsb, int ldh,
-                                                     float* __restrict__ ds, int B, int T, int H, int D) {
+                                                     float* __restrict__ ds, int B, int T, int H, int D,
+                                                     float* __restrict__ zero_out, int zero_n) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    // optional: clear a small accumulator of the kernels that follow (dw2 | db2 of the attention backward) -- saves their fill
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < zero_n; i += 256) zero_out[i] = 0.f;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, q = lane >> 4;
@@ -158,10 +162,10 @@ hipError_t bmm_rows_launch(const float* W, long wsb, long wsi, long wsj, const f
 }
 
 hipError_t rowdot_launch(const float* g, long gsb, int ldg, const float* h, long hsb, int ldh, float* ds,
-                         int B, int T, int H, int D, hipStream_t st) {
-    if (B <= 0) return hipSuccess;
+                         int B, int T, int H, int D, float* zero_out, int zero_n, hipStream_t st) {
+    if (B <= 0) return zero_n > 0 ? hipMemsetAsync(zero_out, 0, (size_t)zero_n * sizeof(float), st) : hipSuccess;
     const long tiles = (long)B * ((T + 15) / 16);
-    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, g, gsb, ldg, h, hsb, ldh, ds, B, T, H, D);
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, g, gsb, ldg, h, hsb, ldh, ds, B, T, H, D, zero_out, zero_n);
     return hipGetLastError();
 }
 

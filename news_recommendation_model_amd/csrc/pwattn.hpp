@@ -55,7 +55,7 @@ struct BwdEPlan { int DT, KT, ndcol, nkw, nsplit, gps; };
 BwdEPlan bwd_e_plan(int D, int G, int target_waves, int min_gps = 1, int mma = 0);
 hipError_t bwd_e_launch(const BwdEParams& p, const BwdEPlan& pl, bool with_dw, int mma, hipStream_t st);
 // dz_format: 0 = fp32 dz in place, 1 = NRM_DZ_HL4 (every aligned group of 4 values as 4 bf16 hi + 4 bf16 lo, in place)
-hipError_t bwd_dz_launch(float* z, const float* ds, const float* w2, float* dw2, float* du, float* dv,
+hipError_t bwd_dz_launch(float* z, const float* ds, const float* w2, float* dw2, float* db2, float* du, float* dv,
                          int B, int T, int H, int D, int dz_format, hipStream_t st);
 
 // ---- backward of the bilinear term, resident-W form for the bf16 arithmetics (pwattn_bwd_rw.hip): dt and dh from ONE read of dz

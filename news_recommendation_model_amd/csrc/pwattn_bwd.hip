@@ -54,7 +54,7 @@ constexpr int DZ_MAXIT = 5;      // history rows per thread and candidate held i
 
 __global__ __launch_bounds__(256) void bwd_dz_kernel(float* __restrict__ z, const float* __restrict__ ds,
                                                      const float* __restrict__ w2, float* __restrict__ dw2,
-                                                     float* __restrict__ du, float* __restrict__ dv,
+                                                     float* __restrict__ db2, float* __restrict__ du, float* __restrict__ dv,
                                                      int T, int Hall, int D, int slab_cols, int hchunk, int fmt) {
     extern __shared__ __attribute__((aligned(16))) float sm[];       // [H][nx] du slab | 2 x [256] float4 exchange
     const int nx = slab_cols >> 2, ny = 256 / nx;
@@ -80,6 +80,8 @@ __global__ __launch_bounds__(256) void bwd_dz_kernel(float* __restrict__ z, cons
     if (ty < ny)
         for (int h = ty; h < H; h += ny) du_l[h * nx + tx] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 aw = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ab = 0.f;                                                  // db2 = sum ds: counted once, by column 0 of slab 0
+    const bool sum_ds = db2 != nullptr && slab == 0 && tx == 0;
     // rows hb + u*ny (u < DZ_MAXIT) of candidate t: request everything, then compute -- and the requests of candidate
     // t+1 go out before the arithmetic of candidate t (two register buffers, the t loop is unrolled by two)
     auto load_rows = [&](int t, int hb, f32x4 (&zz)[DZ_MAXIT], float (&g)[DZ_MAXIT]) {
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(256) void bwd_dz_kernel(float* __restrict__ z, cons
             const int h = hb + u * ny;
             if (cok && h < H) {
                 f32x4 dz;
+                if (sum_ds) ab += g[u];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const GeluParts gp = gelu_parts(zz[u][e]);
@@ -179,9 +182,20 @@ __global__ __launch_bounds__(256) void bwd_dz_kernel(float* __restrict__ z, cons
 #pragma unroll
         for (int e = 0; e < 4; ++e) atomicAdd(dw2 + col + e, sum[e]);
     }
+    if (db2 != nullptr && slab == 0) {                               // uniform per workgroup
+        __syncthreads();
+        float* redf = reinterpret_cast<float*>(red);
+        if (tx == 0) redf[ty] = ab;
+        __syncthreads();
+        if (tid == 0) {
+            float sum = 0.f;
+            for (int y = 0; y < ny; ++y) sum += redf[y];
+            atomicAdd(db2, sum);
+        }
+    }
 }
 
-hipError_t bwd_dz_launch(float* z, const float* ds, const float* w2, float* dw2, float* du, float* dv,
+hipError_t bwd_dz_launch(float* z, const float* ds, const float* w2, float* dw2, float* db2, float* du, float* dv,
                          int B, int T, int H, int D, int dz_format, hipStream_t st) {
     if (B <= 0) return hipSuccess;
     int nslab = (D + 127) / 128;
@@ -208,7 +222,7 @@ hipError_t bwd_dz_launch(float* z, const float* ds, const float* w2, float* dw2,
         hipError_t e = hipMemsetAsync(dv, 0, (size_t)B * T * D * sizeof(float), st);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(bwd_dz_kernel, dim3((D + slab_cols - 1) / slab_cols, B, nhc), dim3(256), shm, st, z, ds, w2, dw2, du, dv,
+    hipLaunchKernelGGL(bwd_dz_kernel, dim3((D + slab_cols - 1) / slab_cols, B, nhc), dim3(256), shm, st, z, ds, w2, dw2, db2, du, dv,
                        T, H, D, slab_cols, hchunk, dz_format);
     return hipGetLastError();
 }

@@ -148,8 +148,12 @@ class UserInvariantInterestModel(nn.Module):
             # same error as the reference, whose feature_embedding reshapes with a -1 dimension (:59); the ops below
             # would accept empty inputs (ops._degenerate), the drop-in keeps the reference's behaviour
             raise RuntimeError("cannot reshape tensor of 0 elements (empty batch / history / candidate list)")
-        lab_h, ti_h = self._embed(x_history, True)         # [B,H,D_l+2], [B,H,P]
-        lab_t, ti_t = self._embed(x_target, False)         # [B,T,D_l],   [B,T,P]
+        # [B,H,D_l+2], [B,H,P], [B,T,D_l], [B,T,P]: both row sets through one autograd node (their table gradients share one arena)
+        sen = self.sentiment_embedding[0]
+        lab_h, ti_h, lab_t, ti_t = ops.frontend_pair(
+            x_history, x_target, self._dims.n_subcat, self._dims.pca_vector, self.category_embedding[0].weight, sen.weight, sen.bias,
+            self.type_embedding[0].weight, self.year_embedding[0].weight, self.month_embedding[0].weight,
+            self.day_embedding[0].weight, self.hour_embedding[0].weight)
         lab_h = ops.linear(lab_h, self.w1.weight, self.w1.bias)
         ec = ops.concat_last((lab_t, ti_t))
 
@@ -176,8 +180,13 @@ class UserInvariantInterestModel(nn.Module):
 
     @staticmethod
     def _attend_and_pool(attention, t, h):
-        s = attention(t, h)                                            # [B,T,H,1]
         # un-normalised weighted pool: sum_h score * history  (no softmax, padding not masked)
+        mlp = getattr(attention, "mlp", None)
+        if type(attention) is PointwiseAttentionExpanded and isinstance(mlp, MLP) and isinstance(mlp.activation, nn.GELU) \
+                and mlp.activation.approximate == "none" and t.dim() == 3:
+            # scores + pool as one autograd node (the backward chains their kernels: ops._attend_pool_bwd_impl)
+            return ops.attend_and_pool(t, h, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias, mma=attention.mma)
+        s = attention(t, h)                                            # [B,T,H,1]
         return ops.weighted_pool(s.squeeze(-1), h)
 
     two_streams = None          # None: by size; True / False force it (env NRM_BRANCH_STREAMS=0|1 overrides both)

@@ -11,7 +11,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NRM_HOTPATH_LIB") or os.path.join(_HERE, "libnrm_hotpath.so")   # override: diagnostic builds (scripts/_diag)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_fp = ctypes.c_void_p      # device pointers travel as integers
 _c_i, _c_l = ctypes.c_int, ctypes.c_long
@@ -24,7 +24,7 @@ SIGNATURES = {
     "nrm_pwattn_packed_floats": (_c_l, [_c_i]),
     "nrm_pwattn_pack_wp": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp]),
     "nrm_pwattn_fwd": (_c_i, [_c_fp] * 9 + [_c_i] * 5 + [_c_fp]),
-    "nrm_pwattn_bwd_dz": (_c_i, [_c_fp] * 6 + [_c_i] * 5 + [_c_fp]),
+    "nrm_pwattn_bwd_dz": (_c_i, [_c_fp] * 7 + [_c_i] * 5 + [_c_fp]),
     "nrm_pwattn_bwd_rw_supported": (_c_i, [_c_i, _c_i]),
     "nrm_pwattn_bwd_rw_packed_floats": (_c_l, [_c_i, _c_i]),
     "nrm_pwattn_bwd_rw_pack": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp]),
@@ -47,8 +47,8 @@ SIGNATURES = {
     "nrm_bn_apply": (_c_i, [_c_fp] * 6 + [_c_i] * 3 + [_c_fp]),
     "nrm_bn_backward": (_c_i, [_c_fp] * 9 + [_c_i] * 4 + [_c_fp]),
     "nrm_concat_cols": (_c_i, [_c_fp, _c_fp, _c_fp, _c_i, _c_fp, _c_i, _c_l, _c_fp]),
-    "nrm_pool_bmm": (_c_i, [_c_fp, _c_l, _c_l, _c_l, _c_fp, _c_fp] + [_c_i] * 5 + [_c_fp]),
-    "nrm_pool_rowdot": (_c_i, [_c_fp] * 3 + [_c_i] * 4 + [_c_fp]),
+    "nrm_pool_bmm": (_c_i, [_c_fp, _c_l, _c_l, _c_l, _c_fp, _c_i, _c_fp] + [_c_i] * 5 + [_c_fp]),
+    "nrm_pool_rowdot": (_c_i, [_c_fp, _c_i, _c_fp, _c_fp] + [_c_i] * 4 + [_c_fp, _c_i, _c_fp]),
     "nrm_loss_fwd_bwd": (_c_i, [_c_fp] * 4 + [_c_l, ctypes.c_float, _c_i, _c_i] + [_c_fp] * 5),
     "nrm_adam_step": (_c_i, [_c_fp] * 4 + [_c_l] + [ctypes.c_float] * 5 + [_c_i, _c_i, _c_fp]),
     "nrm_adam_step_dev": (_c_i, [_c_fp] * 4 + [_c_l] + [ctypes.c_float] * 5 + [_c_fp, _c_i, _c_fp]),

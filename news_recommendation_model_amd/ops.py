@@ -463,9 +463,20 @@ pwattn_fwd = _op("pwattn_fwd", "(Tensor t, Tensor h, Tensor fc1_weight, Tensor f
                  "bool save_z, int mma) -> (Tensor, Tensor)", _pwattn_fwd_impl, _pwattn_fwd_fake)
 
 
-def _pwattn_bwd_impl(ds, t, h, w1, w2, z, mma):
+def _pwattn_bwd_impl(ds, t, h, w1, w2, z, mma, need_dt, need_dh):
     """All gradients of one attention from ds [B,T,H] and the saved pre-activation z [B,T,H,D], which is overwritten
     in place by dz (schema: Tensor(a!))."""
+    return _attn_bwd_core(ds, t, h, w1, w2, z, mma, need_dt, need_dh)
+
+
+def _attn_bwd_core(ds, t, h, w1, w2, z, mma, need_dt=True, need_dh=True, acc=None):
+    """``need_dt`` / ``need_dh``: whether the target / history rows want a gradient.  The text+image attention of the model reads
+    raw input columns (reference user_invariant_interest_model.py:63-64,78: no parameter upstream), so autograd asks for neither
+    -- as in the reference, where those products are never formed -- and the (b,h)-grouped contraction pass, the two
+    side-projection GEMMs and the dt epilogue are skipped: the weight gradients only need dz, du, dv and the dW_p pass.
+    Skipped gradients are returned as empty tensors.
+    ``acc``: [D + 4] floats (dw2 | db2 | pad) that an earlier launch on this stream has ALREADY zeroed (the pool's rowdot
+    kernel in the merged pool + attention backward); None: allocated and zeroed here."""
     _require_gpu(ds, t, h, w1, w2, z)
     B, T, D = t.shape
     H = h.shape[1]
@@ -475,17 +486,18 @@ def _pwattn_bwd_impl(ds, t, h, w1, w2, z, mma):
     own = w1 if w1 is w1_arg else None
     w2v = _f32c(w2).reshape(-1)
     dev = t.device
-    dw2 = torch.zeros(D, dtype=torch.float32, device=dev)
+    if acc is None:
+        acc = torch.zeros(D + 4, dtype=torch.float32, device=dev)
+    dw2, db2 = acc[:D], acc[D:D + 1]                   # the dz pass accumulates both (db2 = sum ds); returned as ONE tensor
     # one pass over z: z -> dz in place, du = sum_t dz, dv = sum_h dz, dw2.  The bf16 arithmetics with a resident-W backward
     # (D <= 256) get dz as bf16 hi/lo pairs (NRM_DZ_HL4): the contraction kernels then read MFMA-ready operands
     lib = native.load()
     rw = mma != MMA_F32 and bool(lib.nrm_pwattn_bwd_rw_supported(D, mma))
     du = torch.empty(B, H, D, dtype=torch.float32, device=dev)
     dv = torch.empty(B, T, D, dtype=torch.float32, device=dev)
-    native.call("nrm_pwattn_bwd_dz", native.ptr(z), native.ptr(ds), native.ptr(w2v), native.ptr(dw2),
+    native.call("nrm_pwattn_bwd_dz", native.ptr(z), native.ptr(ds), native.ptr(w2v), native.ptr(dw2), native.ptr(db2),
                 native.ptr(du), native.ptr(dv), B, T, H, D, DZ_HL4 if rw else DZ_F32, st)
     dz = z
-    db2 = ds.sum().reshape(1)
     w_h, w_t, w_d = w1[:, :D], w1[:, D:2 * D], w1[:, 2 * D:3 * D]
     du2, dv2 = du.reshape(B * H, D), dv.reshape(B * T, D)
     # fc1 gradient [D, 4D] = [da_h | da_t | da_t - da_h | dW_p]: every block is written in place by a slab reduction
@@ -503,40 +515,51 @@ def _pwattn_bwd_impl(ds, t, h, w1, w2, z, mma):
             for x in (ws, cs, ws2):
                 x.record_stream(ctx.main)
     # du (W_h - W_d), dv (W_t + W_d): the transposed orientation of the same two combinations   (D % 4 == 0: contiguous results)
-    dh = _gemm_nt(du2, w_h, 1, 4 * D, D, D, None, EPI_BIAS, src2=w_d, sign2=-1.0, owner=own, mma=mma)[0].reshape(B, H, D)
-    dt = _gemm_nt(dv2, w_t, 1, 4 * D, D, D, None, EPI_BIAS, src2=w_d, sign2=1.0, owner=own, mma=mma)[0].reshape(B, T, D)
+    none = torch.empty(0, dtype=torch.float32, device=dev)
+    dh = (_gemm_nt(du2, w_h, 1, 4 * D, D, D, None, EPI_BIAS, src2=w_d, sign2=-1.0, owner=own, mma=mma)[0].reshape(B, H, D)
+          if need_dh else none)
+    dt = (_gemm_nt(dv2, w_t, 1, 4 * D, D, D, None, EPI_BIAS, src2=w_d, sign2=1.0, owner=own, mma=mma)[0].reshape(B, T, D)
+          if need_dt else none)
     nsplit = lib.nrm_pwattn_bwd_nsplit(B, T, H, D, mma)
     wsp = torch.empty(nsplit, D, D, dtype=torch.float32, device=dev)
     wp = w1[:, 3 * D:]                                   # view, row stride 4D
     if rw:
         # resident-W form: dt and dh from ONE contraction dP = dz W_p (dz read once), then the (b,t)-grouped pass without its dt
         # epilogue for the dW_p slabs
-        img = torch.empty(lib.nrm_pwattn_bwd_rw_packed_floats(D, mma), dtype=torch.float32, device=dev)
-        native.call("nrm_pwattn_bwd_rw_pack", native.ptr(w1), 4 * D, D, mma, native.ptr(img), st)
-        native.call("nrm_pwattn_bwd_rw_dtdh", native.ptr(dz), native.ptr(t), native.ptr(h), native.ptr(img), native.ptr(dt),
-                    native.ptr(dh), B, T, H, D, mma, st, tag="pwattn_bwd_rw_dtdh")
+        if need_dt or need_dh:
+            img = torch.empty(lib.nrm_pwattn_bwd_rw_packed_floats(D, mma), dtype=torch.float32, device=dev)
+            native.call("nrm_pwattn_bwd_rw_pack", native.ptr(w1), 4 * D, D, mma, native.ptr(img), st)
+            # (one of the two unwanted: the kernel forms both anyway; the unwanted one goes to a scratch buffer)
+            dt_ = dt if need_dt else torch.empty(B, T, D, dtype=torch.float32, device=dev)
+            dh_ = dh if need_dh else torch.empty(B, H, D, dtype=torch.float32, device=dev)
+            native.call("nrm_pwattn_bwd_rw_dtdh", native.ptr(dz), native.ptr(t), native.ptr(h), native.ptr(img), native.ptr(dt_),
+                        native.ptr(dh_), B, T, H, D, mma, st, tag="pwattn_bwd_rw_dtdh")
         native.call("nrm_pwattn_bwd_contract", native.ptr(dz), native.ptr(t), native.ptr(h), native.ptr(wp), 4 * D, None, None,
                     native.ptr(wsp), B, T, H, D, 4, mma, DZ_HL4, st, tag="pwattn_bwd_e_bt")
     else:
         # two launches: (b,t)-grouped -> dt + dW_p slabs, (b,h)-grouped -> dh (issued separately so that
-        # bench.py can time each kernel with its own event pair)
+        # bench.py can time each kernel with its own event pair); the second one only when the history wants a gradient
+        dt_ = dt if need_dt else torch.empty(B, T, D, dtype=torch.float32, device=dev)      # scratch for the pass's dt epilogue
         for passes, tag in ((1, "pwattn_bwd_e_bt"), (2, "pwattn_bwd_e_bh")):
+            if passes == 2 and not need_dh:
+                continue
             native.call("nrm_pwattn_bwd_contract", native.ptr(dz), native.ptr(t), native.ptr(h),
-                        native.ptr(wp), 4 * D, native.ptr(dt), native.ptr(dh), native.ptr(wsp), B, T, H, D,
+                        native.ptr(wp), 4 * D, native.ptr(dt_), native.ptr(dh) if need_dh else None, native.ptr(wsp), B, T, H, D,
                         passes, mma, DZ_F32, st, tag=tag)
     _slab_reduce(wsp, nsplit, D, D, D, dw1[:, 3 * D:], 4 * D, 1, target=w1_arg)    # slabs hold dW_p^T: ws[s][d][k] -> dw1[k, 3D + d]
-    return dt, dh, dw1, db1, dw2, db2
+    return dt, dh, dw1, db1, acc
 
 
-def _pwattn_bwd_fake(ds, t, h, w1, w2, z, mma):
+def _pwattn_bwd_fake(ds, t, h, w1, w2, z, mma, need_dt=True, need_dh=True):
     B, T, D = t.shape
     H = h.shape[1]
     f = lambda *shape: t.new_empty(shape, dtype=torch.float32)      # noqa: E731
-    return f(B, T, D), f(B, H, D), f(D, 4 * D), f(D), f(D), f(1)
+    return (f(B, T, D) if need_dt else f(0)), (f(B, H, D) if need_dh else f(0)), f(D, 4 * D), f(D), f(D + 4)
 
 
-pwattn_bwd = _op("pwattn_bwd", "(Tensor ds, Tensor t, Tensor h, Tensor fc1_weight, Tensor fc2_weight, Tensor(a!) z, int mma) -> "
-                 "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)", _pwattn_bwd_impl, _pwattn_bwd_fake)
+# returns (dt, dh, d fc1_weight, d fc1_bias, [d fc2_weight (D) | d fc2_bias (1) | pad (3)])
+pwattn_bwd = _op("pwattn_bwd", "(Tensor ds, Tensor t, Tensor h, Tensor fc1_weight, Tensor fc2_weight, Tensor(a!) z, int mma, "
+                 "bool need_dt, bool need_dh) -> (Tensor, Tensor, Tensor, Tensor, Tensor)", _pwattn_bwd_impl, _pwattn_bwd_fake)
 
 
 def _pwattn_setup(ctx, inputs, output):
@@ -565,8 +588,11 @@ def _pwattn_backward(ctx, ds, _dz):
                            "re-run the forward instead of retain_graph=True")
     ctx.consumed = True
     t, h, w1, w2, z = ctx.saved_tensors
-    dt, dh, dw1, db1, dw2, db2 = pwattn_bwd(ds, t, h, w1, w2, z.detach(), ctx.mma)
-    return dt, dh, dw1, db1, dw2.reshape(ctx.w2_shape), db2.reshape(ctx.b2_shape), None, None
+    need = ctx.needs_input_grad
+    dt, dh, dw1, db1, dw2b2 = pwattn_bwd(ds, t, h, w1, w2, z.detach(), ctx.mma, bool(need[0]), bool(need[1]))
+    D = t.shape[2]
+    return ((dt if need[0] else None), (dh if need[1] else None), dw1, db1, dw2b2[:D].reshape(ctx.w2_shape),
+            dw2b2[D:D + 1].reshape(ctx.b2_shape), None, None)
 
 
 torch.library.register_autograd("nrm::pwattn_fwd", _pwattn_backward, setup_context=_pwattn_setup, lib=_LIB)
@@ -852,9 +878,10 @@ def _bn_bwd_impl(dy, x, mean, rstd, weight, training, add=None):
         buf[:, :N] = dy
         dy = buf[:, :N]
     w = _f32c(weight)
-    s = torch.zeros(2, N, dtype=torch.float32, device=dev)
+    s0 = torch.zeros(N, dtype=torch.float32, device=dev)           # d beta, d gamma: two outputs, two allocations (outputs of
+    s1 = torch.zeros(N, dtype=torch.float32, device=dev)           # an op must not share storage)
     native.call("nrm_colreduce", 2, native.ptr(x), native.ptr(dy), native.ptr(mean), native.ptr(rstd),
-                native.ptr(s[0]), native.ptr(s[1]), R, N, ld, st)
+                native.ptr(s0), native.ptr(s1), R, N, ld, st)
     dx = torch.empty(R, ld, dtype=torch.float32, device=dev)
     if add is not None and not (add.dim() == 2 and add.stride(1) == 1 and add.stride(0) == ld and add.dtype == torch.float32
                                 and add.data_ptr() % 16 == 0):
@@ -862,9 +889,9 @@ def _bn_bwd_impl(dy, x, mean, rstd, weight, training, add=None):
         buf[:, :N] = add
         add = buf[:, :N]
     native.call("nrm_bn_backward", native.ptr(x), native.ptr(dy), native.ptr(mean), native.ptr(rstd), native.ptr(w),
-                native.ptr(s[0]), native.ptr(s[1]), native.ptr(add) if add is not None else None, native.ptr(dx), R, N, ld,
+                native.ptr(s0), native.ptr(s1), native.ptr(add) if add is not None else None, native.ptr(dx), R, N, ld,
                 1 if training else 0, st)
-    return dx[:, :N], s[1].clone(), s[0].clone()
+    return dx[:, :N], s1, s0
 
 
 def _bn_bwd_fake(dy, x, mean, rstd, weight, training):
@@ -1043,7 +1070,7 @@ def _pool_fwd_impl(s, h):
     B, T, H = s.shape
     D = h.shape[2]
     out = torch.empty(B, T, D, dtype=torch.float32, device=h.device)
-    native.call("nrm_pool_bmm", native.ptr(s), T * H, H, 1, native.ptr(h), native.ptr(out), B, T, H, D, 0,
+    native.call("nrm_pool_bmm", native.ptr(s), T * H, H, 1, native.ptr(h), D, native.ptr(out), B, T, H, D, 0,
                 native.stream_ptr())
     return out
 
@@ -1052,16 +1079,28 @@ weighted_pool_fwd = _op("weighted_pool_fwd", "(Tensor scores, Tensor history) ->
                         lambda s, h: s.new_empty((s.shape[0], s.shape[1], h.shape[2]), dtype=torch.float32))
 
 
+def _pooled_grad_rows(g, B, T, D):
+    """The pooled gradient [B,T,D] as (tensor, row stride): a column block of a wider row-major matrix (the head gradient's
+    slice, as concat's backward hands it over) is read in place; anything else is made contiguous."""
+    g = g if g.dtype == torch.float32 else g.to(torch.float32)
+    ld = g.stride(1) if T > 1 else (g.stride(0) if B > 1 else D)
+    if (g.dim() == 3 and g.stride(2) == 1 and ld >= D and ld % 4 == 0 and (B == 1 or g.stride(0) == T * ld)
+            and (T == 1 or g.stride(1) == ld) and g.data_ptr() % 16 == 0 and T * ld * 4 < (1 << 31)):
+        return g, ld
+    return g.contiguous(), D
+
+
 def _pool_bwd_impl(g, s, h):
     _require_gpu(g, s, h)
-    s, h, g = _f32c(s), _f32c(h), _f32c(g)
+    s, h = _f32c(s), _f32c(h)
     B, T, H = s.shape
     D = h.shape[2]
+    g, ldg = _pooled_grad_rows(g, B, T, D)
     st = native.stream_ptr()
     ds = torch.empty(B, T, H, dtype=torch.float32, device=h.device)
-    native.call("nrm_pool_rowdot", native.ptr(g), native.ptr(h), native.ptr(ds), B, T, H, D, st)
+    native.call("nrm_pool_rowdot", native.ptr(g), ldg, native.ptr(h), native.ptr(ds), B, T, H, D, None, 0, st)
     dh = torch.empty(B, H, D, dtype=torch.float32, device=h.device)
-    native.call("nrm_pool_bmm", native.ptr(s), T * H, 1, H, native.ptr(g), native.ptr(dh), B, H, T, D, 0, st)
+    native.call("nrm_pool_bmm", native.ptr(s), T * H, 1, H, native.ptr(g), ldg, native.ptr(dh), B, H, T, D, 0, st)
     return ds, dh
 
 
@@ -1089,6 +1128,96 @@ def weighted_pool(scores, history):
     if D % 4 == 0:
         return weighted_pool_fwd(scores, history)
     return weighted_pool_fwd(scores, torch.nn.functional.pad(history.to(torch.float32), (0, _pad4(D) - D)))[..., :D]
+
+
+# ------------------------------------------------------------------------------------------------ attention + pool, one node
+def _attend_pool_fwd_impl(t, h, w1, b1, w2, b2, save_z, mma):
+    """pooled[b,t,:] = sum_h s[b,t,h] h[b,h,:] with s = the pointwise attention scores: the two calls of
+    user_invariant_interest_model.py:83-87 as ONE autograd node, so that its backward can chain the pool's and the
+    attention's kernels (see _attend_pool_bwd_impl)."""
+    s, z = _pwattn_fwd_impl(t, h, w1, b1, w2, b2, save_z, mma)
+    return _pool_fwd_impl(s, h), s, z
+
+
+def _attend_pool_fwd_fake(t, h, w1, b1, w2, b2, save_z, mma):
+    s, z = _pwattn_fwd_fake(t, h, w1, b1, w2, b2, save_z, mma)
+    return t.new_empty(tuple(t.shape), dtype=torch.float32), s, z
+
+
+attend_pool_fwd = _op("attend_pool_fwd", "(Tensor t, Tensor h, Tensor fc1_weight, Tensor fc1_bias, Tensor fc2_weight, Tensor fc2_bias, "
+                      "bool save_z, int mma) -> (Tensor, Tensor, Tensor)", _attend_pool_fwd_impl, _attend_pool_fwd_fake)
+
+
+def _attend_pool_bwd_impl(g, t, h, w1, w2, s, z, mma, need_dt, need_dh):
+    """Backward of pool + attention from the pooled gradient g [B,T,D] (read in place when it is a column block of the head
+    gradient).  Compared with the two separate nodes: the pool's rowdot launch also clears the attention's dw2 | db2
+    accumulators, and the pool's history gradient is ADDED onto the attention's by the last launch -- no fill, no [B,T,D]
+    copy of g, no [B,H,D] add by autograd."""
+    _require_gpu(g, t, h, w1, w2, s, z)
+    B, T, D = t.shape
+    H = h.shape[1]
+    s, h = _f32c(s), _f32c(h)
+    g, ldg = _pooled_grad_rows(g, B, T, D)
+    st = native.stream_ptr()
+    dev = h.device
+    acc = torch.empty(D + 4, dtype=torch.float32, device=dev)
+    ds = torch.empty(B, T, H, dtype=torch.float32, device=dev)
+    native.call("nrm_pool_rowdot", native.ptr(g), ldg, native.ptr(h), native.ptr(ds), B, T, H, D, native.ptr(acc), D + 4, st)
+    dt, dh, dw1, db1, dw2b2 = _attn_bwd_core(ds, t, h, w1, w2, z, mma, need_dt, need_dh, acc=acc)
+    if need_dh:
+        native.call("nrm_pool_bmm", native.ptr(s), T * H, 1, H, native.ptr(g), ldg, native.ptr(dh), B, H, T, D, 1, st)
+    return dt, dh, dw1, db1, dw2b2
+
+
+attend_pool_bwd = _op("attend_pool_bwd", "(Tensor g, Tensor t, Tensor h, Tensor fc1_weight, Tensor fc2_weight, Tensor s, Tensor(a!) z, "
+                      "int mma, bool need_dt, bool need_dh) -> (Tensor, Tensor, Tensor, Tensor, Tensor)", _attend_pool_bwd_impl,
+                      lambda g, t, h, w1, w2, s, z, mma, need_dt, need_dh: _pwattn_bwd_fake(s, t, h, w1, w2, z, mma, need_dt, need_dh))
+
+
+def _attend_pool_setup(ctx, inputs, output):
+    t, h, w1, b1, w2, b2, save_z, mma = inputs
+    pooled, s, z = output
+    ctx.set_materialize_grads(False)
+    ctx.save_z = save_z
+    ctx.mma = mma
+    ctx.consumed = False
+    ctx.w2_shape, ctx.b2_shape = tuple(w2.shape), tuple(b2.shape)
+    ctx.mark_non_differentiable(s, z)
+    if save_z:
+        ctx.save_for_backward(t, h, w1, w2, s, z)
+
+
+def _attend_pool_backward(ctx, g, _ds, _dz):
+    if g is None:
+        return None, None, None, None, None, None, None, None
+    if not ctx.save_z:
+        raise RuntimeError("pointwise attention: the forward ran with save_z=False (no-grad / inference call); there "
+                           "is nothing to differentiate through")
+    if ctx.consumed:
+        raise RuntimeError("pointwise attention: backward through this graph a second time is not supported "
+                           "(the saved pre-activation buffer was consumed by the first backward); "
+                           "re-run the forward instead of retain_graph=True")
+    ctx.consumed = True
+    t, h, w1, w2, s, z = ctx.saved_tensors
+    need = ctx.needs_input_grad
+    dt, dh, dw1, db1, dw2b2 = attend_pool_bwd(g, t, h, w1, w2, s, z.detach(), ctx.mma, bool(need[0]), bool(need[1]))
+    D = t.shape[2]
+    return ((dt if need[0] else None), (dh if need[1] else None), dw1, db1, dw2b2[:D].reshape(ctx.w2_shape),
+            dw2b2[D:D + 1].reshape(ctx.b2_shape), None, None)
+
+
+torch.library.register_autograd("nrm::attend_pool_fwd", _attend_pool_backward, setup_context=_attend_pool_setup, lib=_LIB)
+
+
+def attend_and_pool(target, history, fc1_weight, fc1_bias, fc2_weight, fc2_bias, mma=None):
+    """[B,T,D] x [B,H,D] -> pooled [B,T,D] = weighted_pool(pointwise_attention_scores(...), history) as one autograd node."""
+    D = target.shape[-1]
+    if D % 4 or target.dim() != 3 or target.shape[0] * target.shape[1] * history.shape[1] == 0:
+        return weighted_pool(pointwise_attention_scores(target, history, fc1_weight, fc1_bias, fc2_weight, fc2_bias, mma=mma), history)
+    args = (target, history, fc1_weight, fc1_bias, fc2_weight, fc2_bias)
+    _require_gpu(*args)
+    save_z = torch.is_grad_enabled() and any(a.requires_grad for a in args)
+    return attend_pool_fwd(*args, save_z, resolve_mma(mma))[0]
 
 
 # ------------------------------------------------------------------------------------------------ loss
@@ -1222,6 +1351,13 @@ frontend_fwd = _op("frontend_fwd", f"(Tensor x, bool behaviour, int n_sub, int P
 
 
 def _frontend_bwd_impl(dlab, x, behaviour, n_sub, P, cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab):
+    tabs = (cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab)
+    return _frontend_bwd_into(dlab, x, behaviour, n_sub, P, tabs, None)[1]
+
+
+def _frontend_bwd_into(dlab, x, behaviour, n_sub, P, tabs, arena):
+    """One backward launch of the front end; its float atomics ADD into ``arena`` (None: a fresh zeroed one)."""
+    cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab = tabs
     _require_gpu(dlab, x)
     if x.dtype not in (torch.float32, torch.float64):
         x = x.to(torch.float32)
@@ -1230,31 +1366,29 @@ def _frontend_bwd_impl(dlab, x, behaviour, n_sub, P, cat_tab, sen_w, sen_b, type
     dims = _frontend_dims(cat_tab, sen_w, type_tab, year_tab, month_tab, day_tab, hour_tab)
     n_cat, e0, e1, n_type, e2, n_year, n_month, n_day, n_hour, e3 = dims
     dlab = _rows(dlab)
-    dev = x.device
-    # the eight gradient tables are carved out of ONE zero-initialised buffer (one fill launch instead of eight)
-    shapes = [(n_cat, e0), (e1, sen_w.shape[1]), (e1,), (n_type, e2), (n_year, e3), (n_month, e3), (n_day, e3), (n_hour, e3)]
-    sizes = [_pad4(int(torch.Size(sh).numel())) for sh in shapes]
-    arena = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-    grads, o = [], 0
-    for sh, n in zip(shapes, sizes):
-        grads.append(arena[o:o + int(torch.Size(sh).numel())].view(sh))
-        o += n
+    grads, arena = _frontend_grad_arena(tabs, x.device, arena)
     d_cat, d_sw, d_sb, d_type, d_year, d_month, d_day, d_hour = grads
     native.call("nrm_frontend_bwd", native.ptr(x), 1 if x.dtype == torch.float64 else 0, x.shape[0], x.shape[1], P,
                 n_sub, 1 if behaviour else 0, native.ptr(dlab), dlab.stride(0), native.ptr(sen_w), native.ptr(sen_b),
                 n_cat, e0, e1, n_type, e2, n_year, n_month, n_day, n_hour, e3,
                 native.ptr(d_cat), native.ptr(d_sw), native.ptr(d_sb), native.ptr(d_type),
                 native.ptr(d_year), native.ptr(d_month), native.ptr(d_day), native.ptr(d_hour), native.stream_ptr())
-    return d_cat, d_sw, d_sb, d_type, d_year, d_month, d_day, d_hour
+    return grads, arena
+
+
+def _frontend_arena_floats(tabs):
+    return sum(_pad4(int(t.numel())) for t in tabs)
 
 
 def _frontend_bwd_fake(dlab, x, behaviour, n_sub, P, cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab):
-    return tuple(t.new_empty(tuple(t.shape), dtype=torch.float32)
-                 for t in (cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab))
+    tabs = (cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab)
+    return cat_tab.new_empty((_frontend_arena_floats(tabs),), dtype=torch.float32)
 
 
-frontend_bwd = _op("frontend_bwd", f"(Tensor dlab, Tensor x, bool behaviour, int n_sub, int P, {_FRONT_TABLES}) -> "
-                   "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)", _frontend_bwd_impl, _frontend_bwd_fake)
+# returns ONE buffer holding the eight table gradients back to back (each padded to 4 floats): _frontend_grad_arena(tabs, dev, arena)
+# gives the eight views (an op's outputs must not share storage, so the views are taken outside the op)
+frontend_bwd = _op("frontend_bwd", f"(Tensor dlab, Tensor x, bool behaviour, int n_sub, int P, {_FRONT_TABLES}) -> Tensor",
+                   _frontend_bwd_impl, _frontend_bwd_fake)
 
 
 def _frontend_setup(ctx, inputs, output):
@@ -1267,7 +1401,8 @@ def _frontend_backward(ctx, dlab, _dti):
     if dlab is None:
         return (None,) * 12
     x, *tabs = ctx.saved_tensors
-    return (None, None, None, None) + tuple(frontend_bwd(dlab, x, *ctx.args, *tabs))
+    arena = frontend_bwd(dlab, x, *ctx.args, *tabs)
+    return (None, None, None, None) + _frontend_grad_arena(tabs, arena.device, arena)[0]
 
 
 torch.library.register_autograd("nrm::frontend_fwd", _frontend_backward, setup_context=_frontend_setup, lib=_LIB)
@@ -1284,6 +1419,85 @@ def frontend(x, behaviour, n_sub, P, cat_tab, sen_w, sen_b, type_tab, year_tab, 
     lab, ti = frontend_fwd(x.reshape(B * N, x.shape[2]), bool(behaviour), int(n_sub), int(P), *tabs)
     ti = ti.detach()                                            # a copy of input columns: not differentiable
     return lab.reshape(B, N, -1) if lab.is_contiguous() else lab.unflatten(0, (B, N)), ti.unflatten(0, (B, N))
+
+
+# history + candidate rows through ONE autograd node: the two backward launches accumulate (float atomics) into one zeroed
+# arena, instead of two arenas, two fills and eight adds of autograd
+def _frontend_pair_fwd_impl(xh, xt, n_sub, P, cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab):
+    tabs = (cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab)
+    lab_h, ti_h = _frontend_fwd_impl(xh, True, n_sub, P, *tabs)
+    lab_t, ti_t = _frontend_fwd_impl(xt, False, n_sub, P, *tabs)
+    return lab_h, ti_h, lab_t, ti_t
+
+
+def _frontend_pair_fwd_fake(xh, xt, n_sub, P, *tabs):
+    return _frontend_fwd_fake(xh, True, n_sub, P, *tabs) + _frontend_fwd_fake(xt, False, n_sub, P, *tabs)
+
+
+frontend_pair_fwd = _op("frontend_pair_fwd", f"(Tensor x_history, Tensor x_target, int n_sub, int P, {_FRONT_TABLES}) -> "
+                        "(Tensor, Tensor, Tensor, Tensor)", _frontend_pair_fwd_impl, _frontend_pair_fwd_fake)
+
+
+def _frontend_pair_bwd_impl(dlab_h, dlab_t, xh, xt, n_sub, P, cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab):
+    tabs = (cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab)
+    arena = None
+    for dlab, x, behaviour in ((dlab_h, xh, True), (dlab_t, xt, False)):
+        if dlab is not None:
+            grads, arena = _frontend_bwd_into(dlab, x, behaviour, n_sub, P, tabs, arena)
+    if arena is None:
+        arena = _frontend_grad_arena(tabs, xh.device)[1]
+    return arena
+
+
+def _frontend_grad_arena(tabs, dev, arena=None):
+    """The eight gradient tables carved out of ONE zero-initialised buffer (one fill launch instead of eight)."""
+    cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab = tabs
+    shapes = [tuple(cat_tab.shape), tuple(sen_w.shape), tuple(sen_b.shape), tuple(type_tab.shape), tuple(year_tab.shape),
+              tuple(month_tab.shape), tuple(day_tab.shape), tuple(hour_tab.shape)]
+    sizes = [_pad4(int(torch.Size(sh).numel())) for sh in shapes]
+    if arena is None:
+        arena = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    grads, o = [], 0
+    for sh, n in zip(shapes, sizes):
+        grads.append(arena[o:o + int(torch.Size(sh).numel())].view(sh))
+        o += n
+    return tuple(grads), arena
+
+
+frontend_pair_bwd = _op("frontend_pair_bwd", f"(Tensor? dlab_history, Tensor? dlab_target, Tensor x_history, Tensor x_target, int n_sub, int P, "
+                        f"{_FRONT_TABLES}) -> Tensor", _frontend_pair_bwd_impl,
+                        lambda dh, dt, xh, xt, n_sub, P, *tabs: tabs[0].new_empty((_frontend_arena_floats(tabs),), dtype=torch.float32))
+
+
+def _frontend_pair_setup(ctx, inputs, output):
+    ctx.set_materialize_grads(False)
+    ctx.args = inputs[2:4]
+    ctx.save_for_backward(inputs[0], inputs[1], *inputs[4:])
+
+
+def _frontend_pair_backward(ctx, dlab_h, _dti_h, dlab_t, _dti_t):
+    if dlab_h is None and dlab_t is None:
+        return (None,) * 12
+    xh, xt, *tabs = ctx.saved_tensors
+    arena = frontend_pair_bwd(dlab_h, dlab_t, xh, xt, *ctx.args, *tabs)
+    return (None, None, None, None) + _frontend_grad_arena(tabs, arena.device, arena)[0]
+
+
+torch.library.register_autograd("nrm::frontend_pair_fwd", _frontend_pair_backward, setup_context=_frontend_pair_setup, lib=_LIB)
+
+
+def frontend_pair(x_history, x_target, n_sub, P, cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab):
+    """(x_history [B,H,cols], x_target [B,T,cols]) -> (label rows of the history [B,H,width+2], its text/image rows [B,H,P], label rows
+    of the candidates [B,T,width], their text/image rows [B,T,P]): frontend(x_history, True) and frontend(x_target, False) as one node."""
+    tabs = (cat_tab, sen_w, sen_b, type_tab, year_tab, month_tab, day_tab, hour_tab)
+    B, H, T = x_history.shape[0], x_history.shape[1], x_target.shape[1]
+    if B * H == 0 or B * T == 0 or x_target.shape[0] != B:
+        return frontend(x_history, True, n_sub, P, *tabs) + frontend(x_target, False, n_sub, P, *tabs)
+    _require_gpu(x_history, x_target, cat_tab)
+    lab_h, ti_h, lab_t, ti_t = frontend_pair_fwd(x_history.reshape(B * H, x_history.shape[2]), x_target.reshape(B * T, x_target.shape[2]),
+                                                 int(n_sub), int(P), *tabs)
+    shape = lambda a, n: a.reshape(B, n, -1) if a.is_contiguous() else a.unflatten(0, (B, n))      # noqa: E731
+    return shape(lab_h, H), ti_h.detach().unflatten(0, (B, H)), shape(lab_t, T), ti_t.detach().unflatten(0, (B, T))
 
 
 # ------------------------------------------------------------------------------------------------ evaluation / optimizer
@@ -1320,4 +1534,5 @@ adam_step = _op("adam_step", "(Tensor(a!) param, Tensor(b!) grad, Tensor(c!) exp
 
 OPS = ("pwattn_fwd", "pwattn_bwd", "linear_fwd", "linear_bwd", "mlp_gelu_fwd", "mlp_gelu_bwd", "batch_norm_stats", "batch_norm_apply",
        "batch_norm_bwd", "gate_block_fwd", "gate_block_bwd", "concat_cols",
-       "weighted_pool_fwd", "weighted_pool_bwd", "softmax_bce_loss", "frontend_fwd", "frontend_bwd", "row_auc", "adam_step")
+       "weighted_pool_fwd", "weighted_pool_bwd", "attend_pool_fwd", "attend_pool_bwd", "softmax_bce_loss", "frontend_fwd", "frontend_bwd",
+       "frontend_pair_fwd", "frontend_pair_bwd", "row_auc", "adam_step")
