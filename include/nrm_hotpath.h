@@ -78,8 +78,10 @@ int nrm_pwattn_bwd_nsplit(int B, int T, int H, int D, int mma);
  *                              (TRANSPOSED slabs: sum them over i, then transpose)
  * dt/dh are accumulated into (float atomics), ws is overwritten.
  * passes: bit 0 = the (b,t)-grouped launch (dt, ws), bit 1 = the (b,h)-grouped launch (dh); 3 = both.
- * passes = 4 (bf16 arithmetics, dz in NRM_DZ_HL4): the (b,t)-grouped launch WITHOUT its dt epilogue -- only ws; dt and dh then
- * come from nrm_pwattn_bwd_rw_dtdh.  dz_format names the layout of dz (NRM_DZ_F32 for passes 1..3). */
+ * passes = 4: the (b,t)-grouped launch WITHOUT its dt epilogue -- only ws (dt, dh may be NULL).  For a caller that wants no
+ * row gradients at all (the model's text+image attention reads raw input columns: neither t nor h has a gradient), or -- bf16
+ * arithmetics with dz in NRM_DZ_HL4 -- beside nrm_pwattn_bwd_rw_dtdh, which then delivers dt and dh.
+ * dz_format names the layout of dz (NRM_DZ_HL4 only with passes = 4 and a bf16 arithmetic). */
 int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, const float* wp, int ldwp,
                             float* dt, float* dh, float* ws,
                             int B, int T, int H, int D, int passes, int mma, int dz_format, nrm_stream_t stream);

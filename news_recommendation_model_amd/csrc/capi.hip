@@ -148,11 +148,10 @@ int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, con
     if (int rc = check_dims("nrm_pwattn_bwd_contract", B, T, H, D)) return rc;
     if (int rc = check_mma("nrm_pwattn_bwd_contract", mma)) return rc;
 
-    if (!dz || !t || !h || !wp) return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: null pointer");
     if (passes != 1 && passes != 2 && passes != 3 && passes != 4) return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: passes=%d", passes);
-    if ((passes == 4) != (dz_format == NRM_DZ_HL4) || (dz_format != NRM_DZ_F32 && dz_format != NRM_DZ_HL4))
-        return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: passes=%d with dz_format=%d (the dW_p-only pass, 4, reads NRM_DZ_HL4; the others fp32)", passes, dz_format);
-    if (passes == 4 && mma == NRM_MMA_F32) return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: the dW_p-only pass exists for the bf16 arithmetics");
+    if ((dz_format != NRM_DZ_F32 && dz_format != NRM_DZ_HL4) || (dz_format == NRM_DZ_HL4 && (passes != 4 || mma == NRM_MMA_F32)))
+        return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: passes=%d mma=%d with dz_format=%d (only the dW_p-only pass, 4, of the bf16 arithmetics reads NRM_DZ_HL4)", passes, mma, dz_format);
+    if (!dz || !t || !h || !wp) return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: null pointer");
     if (((passes & 1) && (!dt || !ws)) || ((passes & 2) && !dh) || (passes == 4 && !ws)) return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: null output");
     if (ldwp < D || ldwp % 4) return fail(NRM_EINVAL, "nrm_pwattn_bwd_contract: ldwp=%d", ldwp);
     if (B == 0) return NRM_OK;
@@ -160,7 +159,7 @@ int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, con
     // pass 1: groups (b,t); rows r = h.  X_g = dz[b,t,:,:], Y_g = h[b];  out = dt, scale rows = t
     if ((passes & 1) || passes == 4) {
         nrm::BwdEParams p = {};
-        p.with_dt = passes == 4 ? 0 : 1; p.x_hl4 = passes == 4 ? 1 : 0;
+        p.with_dt = passes == 4 ? 0 : 1; p.x_hl4 = dz_format == NRM_DZ_HL4 ? 1 : 0;
         p.X = dz; p.xs1 = (long)T * HD; p.xs2 = HD; p.xrs = D;
         p.Y = h; p.ys1 = HD; p.yrs = D;
         p.wp = wp; p.ldwp = ldwp; p.srow = t; p.lds_ = D; p.out = dt; p.ldo = D; p.ws = ws;

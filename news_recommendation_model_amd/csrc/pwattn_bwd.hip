@@ -262,11 +262,11 @@ __global__ __launch_bounds__(256, (MMA && KT > 4) || (MMA == 2 && WITH_DW && WIT
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-descriptor builtins: device pass only (keeps the host stub)
     static_assert(KS == DT, "one pass over the whole d range per group (the 3+2 sub-pass split is gone)");
     constexpr bool BF16 = MMA != 0;
-    static_assert(WITH_DT || (WITH_DW && BF16), "the dW-only form exists for the bf16 arithmetics");
+    static_assert(WITH_DT || WITH_DW, "a pass without dt and without dW_p has nothing to do");
     static_assert(!XHL4 || (BF16 && KT == 4), "hl4 operands: bf16 forms on 4x4 tiles");
     // epilogue with the W_p^T reads two tiles ahead (and step 1 of the next group requested after it): pays on 5x5 tiles
     // (C3: 4.57 -> 4.48 ms); on 4x4 tiles the serial one-read-one-FMA form is faster (C5, D = 768: 20.6 vs 23.2 ms)
-    constexpr bool AHEAD = WITH_DW && NRM_EPI_AHEAD && !BF16 && KT == 5;
+    constexpr bool AHEAD = WITH_DT && WITH_DW && NRM_EPI_AHEAD && !BF16 && KT == 5;
     constexpr int LDK = KT * 16 + 8;      // padded row of the W_p^T tile: +8 is conflict-free under gfx950 b128 lane groups (+4 is 2-way)
     __shared__ __attribute__((aligned(16))) float smem[WITH_DT ? DT * 16 * LDK + 4 * DT * 16 : 4];
     float* wpt = smem;                                                  // [DT*16 d][LDK]  = W_p[k0+k][d0+d]
@@ -962,6 +962,17 @@ static hipError_t launch_e_t(BwdEParams p, const BwdEPlan& pl, bool with_dw, int
     if constexpr (KT != 4) {
         if (mma != 0) return hipErrorInvalidValue;      // bwd_e_plan gives the bf16 forms 4x4 tiles only
     } else if (mma == 1 || mma == 2) {
+        if (!p.with_dt && !p.x_hl4) {                   // dW_p only from fp32 dz (no row gradient wanted; D > 256 keeps fp32 dz)
+            if (!with_dw) return hipErrorInvalidValue;
+            if (mma == 1) {
+                if (exact) hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, true, 1, false, false>), grid, block, 0, st, p);
+                else       hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, false, 1, false, false>), grid, block, 0, st, p);
+            } else {
+                if (exact) hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, true, 2, false, false>), grid, block, 0, st, p);
+                else       hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, false, 2, false, false>), grid, block, 0, st, p);
+            }
+            return hipGetLastError();
+        }
         if (!p.with_dt || p.x_hl4) {                    // the dW_p-only pass of the resident-W backward (hl4 dz operand)
             if (!with_dw || p.with_dt || !p.x_hl4) return hipErrorInvalidValue;
             static const bool r32 = [] { const char* e = getenv("NRM_DW_R32"); return !(e && e[0] == '0'); }();
@@ -996,7 +1007,11 @@ static hipError_t launch_e_t(BwdEParams p, const BwdEPlan& pl, bool with_dw, int
 #undef NRM_LAUNCH_E
         return hipGetLastError();
     }
-    if (with_dw) {
+    if (with_dw && !p.with_dt) {                        // fp32, dW_p only (no row gradient wanted)
+        if (p.x_hl4) return hipErrorInvalidValue;
+        if (exact) hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, true, 0, false, false>), grid, block, 0, st, p);
+        else       hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, false, 0, false, false>), grid, block, 0, st, p);
+    } else if (with_dw) {
         if (exact) hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, true>), grid, block, 0, st, p);
         else       hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, false>), grid, block, 0, st, p);
     } else if (pipe_enabled() && (p.R + 3) / 4 >= ((DT + 1) & ~1) + 2) {

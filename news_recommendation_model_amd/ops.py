@@ -539,13 +539,13 @@ def _attn_bwd_core(ds, t, h, w1, w2, z, mma, need_dt=True, need_dh=True, acc=Non
     else:
         # two launches: (b,t)-grouped -> dt + dW_p slabs, (b,h)-grouped -> dh (issued separately so that
         # bench.py can time each kernel with its own event pair); the second one only when the history wants a gradient
-        dt_ = dt if need_dt else torch.empty(B, T, D, dtype=torch.float32, device=dev)      # scratch for the pass's dt epilogue
-        for passes, tag in ((1, "pwattn_bwd_e_bt"), (2, "pwattn_bwd_e_bh")):
+        # (without a target gradient the first one runs without its dt epilogue: passes = 4)
+        for passes, tag in ((1 if need_dt else 4, "pwattn_bwd_e_bt"), (2, "pwattn_bwd_e_bh")):
             if passes == 2 and not need_dh:
                 continue
             native.call("nrm_pwattn_bwd_contract", native.ptr(dz), native.ptr(t), native.ptr(h),
-                        native.ptr(wp), 4 * D, native.ptr(dt_), native.ptr(dh) if need_dh else None, native.ptr(wsp), B, T, H, D,
-                        passes, mma, DZ_F32, st, tag=tag)
+                        native.ptr(wp), 4 * D, native.ptr(dt) if need_dt else None, native.ptr(dh) if need_dh else None,
+                        native.ptr(wsp), B, T, H, D, passes, mma, DZ_F32, st, tag=tag)
     _slab_reduce(wsp, nsplit, D, D, D, dw1[:, 3 * D:], 4 * D, 1, target=w1_arg)    # slabs hold dW_p^T: ws[s][d][k] -> dw1[k, 3D + d]
     return dt, dh, dw1, db1, acc
 

@@ -41,8 +41,8 @@ def test_resident_w_backward_plan(lib):
     assert lib.nrm_pwattn_bwd_rw_supported(256, 2) == 1 and lib.nrm_pwattn_bwd_rw_supported(64, 1) == 1
     assert lib.nrm_pwattn_bwd_rw_supported(256, 0) == 0 and lib.nrm_pwattn_bwd_rw_supported(400, 2) == 0
     assert lib.nrm_pwattn_bwd_rw_packed_floats(256, 2) >= 256 * 256          # hi + lo bf16 images = 4 bytes per weight
-    rc = lib.nrm_pwattn_bwd_contract(None, None, None, None, 256, None, None, None, 2, 3, 4, 64, 4, 2, 0, None)
-    assert rc != 0                                                            # the dW_p-only pass reads NRM_DZ_HL4 only
+    rc = lib.nrm_pwattn_bwd_contract(None, None, None, None, 256, None, None, None, 2, 3, 4, 64, 1, 2, 1, None)
+    assert rc != 0 and b"NRM_DZ_HL4" in lib.nrm_last_error()                  # only the dW_p-only pass (4) reads NRM_DZ_HL4
 
 
 def test_host_validation_rejects_bad_shapes(lib):
