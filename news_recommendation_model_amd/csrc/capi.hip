@@ -472,6 +472,7 @@ int nrm_row_auc(const float* score, const float* label, const int* len, int B, i
 static int check_fe(const char* fn, int nrows, int xcols, int P, int n_sub, int behaviour, int e0, int e1, int e2, int e3) {
     if (nrows < 0 || P <= 0 || n_sub < 0 || e0 <= 0 || e1 <= 0 || e2 <= 0 || e3 <= 0)
         return fail(NRM_EINVAL, "%s: bad dimension", fn);
+    if (n_sub > 16) return fail(NRM_EINVAL, "%s: n_sub=%d (<= 16 sub-category slots)", fn, n_sub);
     const int need = 4 + P + 1 + n_sub + 3 + 1 + (behaviour ? 2 : 0);
     if (xcols < need) return fail(NRM_EINVAL, "%s: packed rows have %d columns, layout needs %d", fn, xcols, need);
     return NRM_OK;

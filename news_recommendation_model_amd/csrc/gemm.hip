@@ -461,6 +461,7 @@ __device__ __forceinline__ void slab_reduce_block(const SlabReduceParams& p, int
         const int i = bx * 256 + ty * 32 + tx;
         if (i < p.ni) {
             float a = 0.f;
+#pragma unroll 8
             for (int s = 0; s < p.nsplit; ++s) a += p.vec[(size_t)s * p.ldws + i];
             p.vec_out[i] = a;
         }
@@ -475,6 +476,7 @@ __device__ __forceinline__ void slab_reduce_block(const SlabReduceParams& p, int
     for (int r = 0; r < 4; ++r) a[r] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int i = i0 + 4 * tx;
     if (i < p.ldws) {                                                   // ldws % 4 == 0: the float4 stays inside the padded row
+#pragma unroll 4
         for (int s = s_lo; s < s_hi; ++s) {
             const float* src = p.ws + s * slab + (size_t)(j0 + ty) * p.ldws + i;
 #pragma unroll
@@ -511,9 +513,12 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceParams
 // before the optimizer reads the gradients (ops.flush_slab_reductions).
 __global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const SlabTable tab) {
     __shared__ float tile[32][129];
-    const int e = blockIdx.z;
-    if ((int)blockIdx.x >= tab.gx[e] || (int)blockIdx.y > tab.nchunk[e]) return;
-    slab_reduce_block(tab.e[e], tab.spc[e], blockIdx.x, blockIdx.y, tab.nchunk[e] + 1, tile);
+    // flat grid: block -> (set, tile, split chunk) through the prefix table (sets differ a lot in their block counts: a 3-D grid
+    // sized for the largest in both directions would be mostly empty blocks)
+    int b = blockIdx.x, e = 0;
+    while (e + 1 < tab.n && b >= tab.first[e + 1]) ++e;
+    b -= tab.first[e];
+    slab_reduce_block(tab.e[e], tab.spc[e], b % tab.gx[e], b / tab.gx[e], tab.nchunk[e] + 1, tile);
 }
 
 static void slab_plan(const SlabReduceParams& p, int& gx, int& nchunk, int& spc) {
@@ -521,9 +526,13 @@ static void slab_plan(const SlabReduceParams& p, int& gx, int& nchunk, int& spc)
     const int tiles = nbi * nbj;
     gx = tiles;
     if (p.vec && (p.ni + 255) / 256 > gx) gx = (p.ni + 255) / 256;
-    nchunk = 4096 / tiles;                                              // ~4096 blocks over the chip ...
-    if (nchunk > 32) nchunk = 32;                                       // ... but at most 32 atomic adds per output element
-    if (nchunk > (p.nsplit + 3) / 4) nchunk = (p.nsplit + 3) / 4;       // (64 x 64 gradients come in 500+ slabs) and >= 4 slabs per block
+    // Blocks = tiles x split chunks.  Every block ends with one float atomic per element of its tile, and float atomics run at
+    // ~65 G/s chip-wide (measured: they, not the slab reads, were most of this kernel -- 32 chunks x 52 tiles at C3 = 6.8 M
+    // atomics), so: about two blocks per CU, each walking its chunk of slabs with several loads in flight (the s loop below is
+    // unrolled by 4).  A 64 x 64 gradient that arrives in 1920 slabs (reference default sizes) gets 128 chunks of 15.
+    nchunk = 512 / tiles;
+    if (nchunk > 128) nchunk = 128;
+    if (nchunk > (p.nsplit + 3) / 4) nchunk = (p.nsplit + 3) / 4;       // >= 4 slabs per block
     if (nchunk < 1) nchunk = 1;
     spc = (p.nsplit + nchunk - 1) / nchunk;
     nchunk = (p.nsplit + spc - 1) / spc;
@@ -541,14 +550,15 @@ hipError_t slab_reduce_multi_launch(const SlabReduceParams* ps, int n, hipStream
     for (int base = 0; base < n; base += SLAB_MAX) {
         SlabTable tab;
         const int m = n - base < SLAB_MAX ? n - base : SLAB_MAX;
-        int gx_max = 1, gy_max = 1;
+        int blocks = 0;
         for (int e = 0; e < m; ++e) {
             tab.e[e] = ps[base + e];
             slab_plan(tab.e[e], tab.gx[e], tab.nchunk[e], tab.spc[e]);
-            if (tab.gx[e] > gx_max) gx_max = tab.gx[e];
-            if (tab.nchunk[e] + 1 > gy_max) gy_max = tab.nchunk[e] + 1;
+            tab.first[e] = blocks;
+            blocks += tab.gx[e] * (tab.nchunk[e] + 1);
         }
-        hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(gx_max, gy_max, m), dim3(32, 8), 0, st, tab);
+        tab.n = m;
+        hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(blocks), dim3(32, 8), 0, st, tab);
         const hipError_t err = hipGetLastError();
         if (err != hipSuccess) return err;
     }

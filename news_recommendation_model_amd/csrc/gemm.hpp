@@ -67,8 +67,8 @@ struct SlabReduceParams {
     const float* vec; float* vec_out;     // [nsplit][ldws] -> [ni], or nullptr
 };
 hipError_t slab_reduce_launch(const SlabReduceParams& p, hipStream_t st);
-constexpr int SLAB_MAX = 24;              // slab sets per multi launch (the table is a kernel argument: 24 x 96 B + 3 x 96 B)
-struct SlabTable { SlabReduceParams e[SLAB_MAX]; int spc[SLAB_MAX]; int nchunk[SLAB_MAX]; int gx[SLAB_MAX]; };
+constexpr int SLAB_MAX = 24;              // slab sets per multi launch (the table is a kernel argument: 24 x 96 B + 4 x 96 B + 4)
+struct SlabTable { SlabReduceParams e[SLAB_MAX]; int spc[SLAB_MAX]; int nchunk[SLAB_MAX]; int gx[SLAB_MAX]; int first[SLAB_MAX]; int n; };
 hipError_t slab_reduce_multi_launch(const SlabReduceParams* ps, int n, hipStream_t st);
 
 }  // namespace nrm
