@@ -337,15 +337,18 @@ __global__ __launch_bounds__(RX_WAVES * 64, RT <= 2 ? RX_WAVES / 2 : RX_WAVES / 
 int gemm_nt_rx_bm(int M, int K, int mma) {
     if (mma != 1 && mma != 2) return 0;
     const int k32 = (K + 31) / 32, wimg = mma == 2 ? 2 : 1;
-    // (blocks of 64 / 128 rows -- RT = 4 / 8 -- are compiled but not used: the RT = 4 form returned wrong rows 12-15 / 28-31 of its
-    // block at M = 51200 and was not debugged; 32-row blocks are what every BASELINE shape of config 2 takes anyway)
+    // (the RT = 4 form once returned wrong rows 12-15 / 28-31 of its block: the store-data hazard of common.hpp's
+    // store_b128_guarded, fixed there; tests/test_gpu_dense.py runs 64-row blocks at M = 15360 and 51200)
     int bm = 128;
     if (const char* e = getenv("NRM_RX_BM")) bm = atoi(e);
     while (bm >= 16 && (long)k32 * wimg * bm * 64 > RX_LDS_BUDGET) bm /= 2;
     if (bm < 16) return 0;                                               // K too wide for a resident row block
     // two workgroups per CU (the conversion prologue of one under the MFMAs of the other) when that keeps >= 32 rows per block
     while (bm > 32 && (long)k32 * wimg * bm * 64 > RX_LDS_BUDGET / 2) bm /= 2;
-    while (bm > 32 && (M + bm - 1) / bm < 480) bm /= 2;                  // ... and enough workgroups to give every CU two
+    // ... and enough workgroups for (nearly) every CU: every workgroup streams ALL weight fragments from L2, so rows per
+    // workgroup are what amortises that traffic (M = 15360, K = 258, N = 1032: 32 -> 64 rows, 59 -> 49 us)
+    static const int min_wgs = [] { const char* e = getenv("NRM_RX_MIN_WGS"); return e ? atoi(e) : 200; }();
+    while (bm > 32 && (M + bm - 1) / bm < min_wgs) bm /= 2;
     while (bm > 16 && M <= bm / 2) bm /= 2;
     return bm;
 }

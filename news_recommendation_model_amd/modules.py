@@ -157,11 +157,11 @@ class UserInvariantInterestModel(nn.Module):
         lab_h = ops.linear(lab_h, self.w1.weight, self.w1.bias)
         ec = ops.concat_last((lab_t, ti_t))
 
-        # The two attentions (label features / text+image vector) share no data until the concat.  When their kernels do not
-        # fill the chip (small B*T*H: C1, C2, the reference's default sizes) the second one is issued on a side stream, so it
-        # overlaps the first -- in eager mode and as two parallel branches of the captured HIP graph; autograd runs every
-        # backward node on the stream of its forward and joins the streams at the end of backward().  Full-size batches (C3,
-        # C5: every launch is several waves of workgroups deep) keep one stream.
+        # The two attentions (label features / text+image vector) share no data until the concat, so the second one is issued on
+        # a side stream and overlaps the first -- in eager mode and as two parallel branches of the captured HIP graph; autograd
+        # runs every backward node on the stream of its forward and joins the streams at the end of backward().  On small
+        # shapes (C1, C2, the reference's default sizes) neither attention fills the chip; on full-size batches the HBM-bound
+        # and the MFMA-bound kernels of the two branches overlap (ops.BRANCH_STREAMS_MAX_ELEMS).
         side = ops.branch_stream(lab_t) if self._two_streams(lab_t, lab_h) else None
         if side is not None:
             main = torch.cuda.current_stream()

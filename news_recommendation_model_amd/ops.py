@@ -1224,9 +1224,12 @@ def attend_and_pool(target, history, fc1_weight, fc1_bias, fc2_weight, fc2_bias,
 _index_error_flag = {}
 
 
-# z elements (B*T*H*D) of one attention up to which UserInvariantInterestModel runs its two attentions on two streams:
-# C2-small (126 M) and smaller overlap, C3 (614 M) and C5 do not
-BRANCH_STREAMS_MAX_ELEMS = 200_000_000
+# z elements (B*T*H*D) of one attention up to which UserInvariantInterestModel runs its two attentions on two streams.  Rounds
+# 1-2 kept C3 (614 M) and C5 on one stream because bench.py timed its kernels inside the timed region; it now takes kernel
+# durations from separate one-stream steps, and with the text+image branch's backward reduced to dz + the dW_p pass (DESIGN.md
+# section 4d) the HBM-bound dz pass of one branch hides under the MFMA-bound contraction of the other: C3 32.2 -> 31.95 ms, C5
+# 119.0 -> 117.3 ms.  So: every size.  (NRM_BRANCH_STREAMS=0 or module.two_streams = False for one stream.)
+BRANCH_STREAMS_MAX_ELEMS = 1 << 62
 _branch_streams = {}
 
 

@@ -218,7 +218,7 @@ def dense_arithmetic():
 # fp32 gates it has to keep for the whole model; plain bf16 (one rounding per operand, 2^-9) is characterised at 3e-2.
 @pytest.mark.parametrize("mma,tol", [("bf16x3", 1e-4), ("bf16", 3e-2)])
 @pytest.mark.parametrize("M,K,N", [(300, 258, 1032), (257, 1032, 258), (64, 3, 8), (1000, 402, 1), (33, 66, 64), (5, 272, 68),
-                                   (4099, 256, 256), (200, 1608, 402), (17, 40, 36), (51200, 64, 64)])
+                                   (4099, 256, 256), (200, 1608, 402), (17, 40, 36), (51200, 64, 64), (15360, 258, 1032)])     # the last two: 128- and 64-row blocks
 @pytest.mark.parametrize("gelu", [False, True])
 def test_linear_forward_backward_on_bf16_matrix_cores(lib, dense_arithmetic, mma, tol, M, K, N, gelu):
     from news_recommendation_model_amd import ops
