@@ -195,13 +195,26 @@ int nrm_pool_bmm(const float* W, long wsb, long wsi, long wsj, const float* X, i
 int nrm_pool_rowdot(const float* g, int ldg, const float* h, float* ds, int B, int T, int H, int D, float* zero_out, int zero_n,
                     nrm_stream_t stream);
 
+/* ---- instant-interest layer (reference models/user_instant_interest_model.py: ReLU(Linear(3 -> 8)) on the popularity scalars
+ * of a candidate).  x [R, K] dense, fp32 or fp64; weight [N, K]; K <= 4, N <= 8.
+ * forward: y [R, ldy] = ReLU(x W^T + b), columns N..ldy-1 written as 0.
+ * backward: dwb[n*K + k] += sum_r g[r,n] x[r,k] and dwb[N*K + n] += sum_r g[r,n] with g = dy (row stride lddy) where the
+ * pre-activation is positive (recomputed from x); dwb (N*K + N floats) must be initialised; x has no gradient. */
+int nrm_small_linear_relu_fwd(const void* x, int x_is_f64, const float* weight, const float* bias, float* y, long R, int K, int N, int ldy,
+                              nrm_stream_t stream);
+int nrm_small_linear_relu_bwd(const void* x, int x_is_f64, const float* weight, const float* bias, const float* dy, int lddy, long R,
+                              int K, int N, float* dwb, nrm_stream_t stream);
+
 /* ---- loss (reference models/user_model.py:37-43): (1-alpha)*BCE(softmax_T(out), y) + alpha*BCE(softmax_T(out +
  * delta[id]), y), mean over B*T, log clamped at -100.  Writes loss_sum[0] += loss, dout [B,T] = dL/dout and
  * ddelta[id[b]] += dL/ddelta (loss_sum and ddelta must be zero-initialised).  T <= 256.  delta has n_delta entries;
  * a negative id counts from the end as in torch indexing, an id still outside [0, n_delta) is clamped and sets
- * err[0] = 1 (the reference raises IndexError at user_model.py:40; never an out-of-bounds access here). */
-int nrm_loss_fwd_bwd(const float* out, const float* label, const long* user_id, const float* delta, long n_delta,
-                     float alpha, int B, int T, float* loss_sum, float* dout, float* ddelta, int* err,
+ * err[0] = 1 (the reference raises IndexError at user_model.py:40; never an out-of-bounds access here).
+ * out_stride / dout_stride: floats between consecutive (b, t) entries -- 1 for dense [B,T]; 4 for the single column of a
+ * zero-padded [B*T, 4] matrix (the layout the logit GEMM writes and the GEMM consuming dout reads; dout then gets (g,0,0,0)).
+ * label: [B,T] dense, fp32 or (label_is_f64) fp64 as the reference's DataLoader yields it. */
+int nrm_loss_fwd_bwd(const float* out, int out_stride, const void* label, int label_is_f64, const long* user_id, const float* delta,
+                     long n_delta, float alpha, int B, int T, float* loss_sum, float* dout, int dout_stride, float* ddelta, int* err,
                      nrm_stream_t stream);
 
 /* ---- Adam over one flat fp32 buffer (reference train.py:48,73-75): g += wd*p; m,v update; bias correction for

@@ -417,11 +417,29 @@ int nrm_pool_rowdot(const float* g, int ldg, const float* h, float* ds, int B, i
     return check_hip(nrm::rowdot_launch(g, (long)T * ldg, ldg, h, (long)H * D, D, ds, B, T, H, D, zero_out, zero_n, (hipStream_t)stream), "pool_rowdot");
 }
 
-int nrm_loss_fwd_bwd(const float* out, const float* label, const long* user_id, const float* delta, long n_delta, float alpha,
-                     int B, int T, float* loss_sum, float* dout, float* ddelta, int* err, nrm_stream_t stream) {
+int nrm_small_linear_relu_fwd(const void* x, int x_is_f64, const float* weight, const float* bias, float* y, long R, int K, int N, int ldy,
+                              nrm_stream_t stream) {
+    if (!x || !weight || !y) return fail(NRM_EINVAL, "nrm_small_linear_relu_fwd: null pointer");
+    if (R < 0 || K < 1 || K > 4 || N < 1 || N > 8 || ldy < N) return fail(NRM_EINVAL, "nrm_small_linear_relu_fwd: R=%ld K=%d N=%d ldy=%d (K <= 4, N <= 8)", R, K, N, ldy);
+    return check_hip(nrm::small_linear_relu_fwd_launch(x, x_is_f64, weight, bias, y, R, K, N, ldy, (hipStream_t)stream), "small_linear_relu_fwd");
+}
+
+int nrm_small_linear_relu_bwd(const void* x, int x_is_f64, const float* weight, const float* bias, const float* dy, int lddy, long R,
+                              int K, int N, float* dwb, nrm_stream_t stream) {
+    if (!x || !weight || !dy || !dwb) return fail(NRM_EINVAL, "nrm_small_linear_relu_bwd: null pointer");
+    if (R < 0 || K < 1 || K > 4 || N < 1 || N > 8 || lddy < N) return fail(NRM_EINVAL, "nrm_small_linear_relu_bwd: R=%ld K=%d N=%d lddy=%d (K <= 4, N <= 8)", R, K, N, lddy);
+    return check_hip(nrm::small_linear_relu_bwd_launch(x, x_is_f64, weight, bias, dy, lddy, R, K, N, dwb, (hipStream_t)stream), "small_linear_relu_bwd");
+}
+
+int nrm_loss_fwd_bwd(const float* out, int out_stride, const void* label, int label_is_f64, const long* user_id, const float* delta,
+                     long n_delta, float alpha, int B, int T, float* loss_sum, float* dout, int dout_stride, float* ddelta, int* err,
+                     nrm_stream_t stream) {
     if (!out || !label || !user_id || !delta || !loss_sum || !dout || !ddelta || !err) return fail(NRM_EINVAL, "nrm_loss_fwd_bwd: null pointer");
     if (B < 0 || T <= 0 || T > 256 || n_delta < 1) return fail(NRM_EINVAL, "nrm_loss_fwd_bwd: B=%d T=%d n_delta=%ld (T <= 256, n_delta >= 1)", B, T, n_delta);
-    return check_hip(nrm::loss_launch(out, label, user_id, delta, n_delta, alpha, B, T, loss_sum, dout, ddelta, err, (hipStream_t)stream), "loss");
+    if (out_stride < 1 || dout_stride < 1 || (dout_stride == 4 && !al16(dout)))
+        return fail(NRM_EINVAL, "nrm_loss_fwd_bwd: out_stride=%d dout_stride=%d (>= 1; dout 16-byte aligned for stride 4)", out_stride, dout_stride);
+    return check_hip(nrm::loss_launch(out, out_stride, label, label_is_f64, user_id, delta, n_delta, alpha, B, T, loss_sum, dout, dout_stride,
+                                      ddelta, err, (hipStream_t)stream), "loss");
 }
 
 int nrm_adam_step(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,

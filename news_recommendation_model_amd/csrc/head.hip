@@ -208,4 +208,91 @@ hipError_t concat_cols_launch(const ConcatTable& tab, float* out, long R, int ld
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// y = ReLU(x W^T + b) for a handful of input and output columns (reference models/user_instant_interest_model.py: the 3
+// popularity scalars of a candidate -> 8 features).  As a GEMM this was a zero-padded copy of x, a K = 4 launch, a clamp --
+// and the same again backwards; here: one thread per row forward, a register reduction over rows backward.
+constexpr int SL_KMAX = 4, SL_NMAX = 8;
+
+template <typename XT>
+__global__ __launch_bounds__(256) void small_linear_relu_fwd_kernel(const XT* __restrict__ x, const float* __restrict__ w,
+                                                                    const float* __restrict__ b, float* __restrict__ y,
+                                                                    long R, int K, int N, int ldy) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    float xk[SL_KMAX];
+#pragma unroll
+    for (int k = 0; k < SL_KMAX; ++k) xk[k] = k < K ? (float)x[r * K + k] : 0.f;
+    float* yr = y + r * ldy;
+    for (int n = 0; n < ldy; ++n) {
+        float v = 0.f;
+        if (n < N) {
+            v = b ? b[n] : 0.f;
+#pragma unroll
+            for (int k = 0; k < SL_KMAX; ++k) if (k < K) v = fmaf(w[n * K + k], xk[k], v);
+            v = fmaxf(v, 0.f);
+        }
+        yr[n] = v;                                                       // padding columns are written as 0
+    }
+}
+
+// dwb[n*K + k] += sum_r g[r,n] x[r,k],  dwb[N*K + n] += sum_r g[r,n],  g = dy where the pre-activation is positive
+template <typename XT>
+__global__ __launch_bounds__(256) void small_linear_relu_bwd_kernel(const XT* __restrict__ x, const float* __restrict__ w,
+                                                                    const float* __restrict__ b, const float* __restrict__ dy,
+                                                                    int lddy, long R, int K, int N, float* __restrict__ dwb) {
+    float acc[SL_NMAX][SL_KMAX + 1];
+#pragma unroll
+    for (int n = 0; n < SL_NMAX; ++n)
+#pragma unroll
+        for (int k = 0; k <= SL_KMAX; ++k) acc[n][k] = 0.f;
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < R; r += (long)gridDim.x * 256) {
+        float xk[SL_KMAX];
+#pragma unroll
+        for (int k = 0; k < SL_KMAX; ++k) xk[k] = k < K ? (float)x[r * K + k] : 0.f;
+#pragma unroll
+        for (int n = 0; n < SL_NMAX; ++n) {
+            if (n < N) {
+                float pre = b ? b[n] : 0.f;
+#pragma unroll
+                for (int k = 0; k < SL_KMAX; ++k) if (k < K) pre = fmaf(w[n * K + k], xk[k], pre);
+                const float g = pre > 0.f ? dy[r * lddy + n] : 0.f;
+#pragma unroll
+                for (int k = 0; k < SL_KMAX; ++k) acc[n][k] = fmaf(g, xk[k], acc[n][k]);
+                acc[n][SL_KMAX] += g;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int n = 0; n < SL_NMAX; ++n)
+#pragma unroll
+        for (int k = 0; k <= SL_KMAX; ++k) {
+            const float v = wave_sum64(acc[n][k]);
+            if (lane == 0 && n < N && (k < K || k == SL_KMAX) && v != 0.f)
+                atomicAdd(dwb + (k == SL_KMAX ? N * K + n : n * K + k), v);
+        }
+}
+
+hipError_t small_linear_relu_fwd_launch(const void* x, int x_is_f64, const float* w, const float* b, float* y, long R, int K, int N,
+                                        int ldy, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    if (K < 1 || K > SL_KMAX || N < 1 || N > SL_NMAX || ldy < N) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((R + 255) / 256));
+    if (x_is_f64) hipLaunchKernelGGL(small_linear_relu_fwd_kernel<double>, grid, dim3(256), 0, st, (const double*)x, w, b, y, R, K, N, ldy);
+    else          hipLaunchKernelGGL(small_linear_relu_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, w, b, y, R, K, N, ldy);
+    return hipGetLastError();
+}
+
+hipError_t small_linear_relu_bwd_launch(const void* x, int x_is_f64, const float* w, const float* b, const float* dy, int lddy,
+                                        long R, int K, int N, float* dwb, hipStream_t st) {
+    if (R <= 0) return hipSuccess;
+    if (K < 1 || K > SL_KMAX || N < 1 || N > SL_NMAX || lddy < N) return hipErrorInvalidValue;
+    long blocks = (R + 255) / 256;
+    if (blocks > 512) blocks = 512;                                      // 40 atomics per wave at the end: keep the waves few and long
+    if (x_is_f64) hipLaunchKernelGGL(small_linear_relu_bwd_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, st, (const double*)x, w, b, dy, lddy, R, K, N, dwb);
+    else          hipLaunchKernelGGL(small_linear_relu_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, w, b, dy, lddy, R, K, N, dwb);
+    return hipGetLastError();
+}
+
 }  // namespace nrm

@@ -17,4 +17,8 @@ hipError_t bn_finalize_launch(int stage, const float* s, float* out, float* runn
                               hipStream_t st);
 hipError_t mul_bwd_launch(const float* dy, const float* g, const float* e, float* dg, float* de, long R, int N,
                           int lddy, int ldg, int lde, int ldo, hipStream_t st);
+hipError_t small_linear_relu_fwd_launch(const void* x, int x_is_f64, const float* w, const float* b, float* y, long R, int K, int N,
+                                        int ldy, hipStream_t st);
+hipError_t small_linear_relu_bwd_launch(const void* x, int x_is_f64, const float* w, const float* b, const float* dy, int lddy,
+                                        long R, int K, int N, float* dwb, hipStream_t st);
 }  // namespace nrm

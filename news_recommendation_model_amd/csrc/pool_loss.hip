@@ -177,10 +177,13 @@ __device__ __forceinline__ float wave_max64(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out, const float* __restrict__ label,
+// out / dout: element (b, t) at [(b*T + t) * stride] -- stride 4 is the single column of a zero-padded [B*T, 4] matrix (what the
+// GEMM that produces the logits writes and the GEMM that consumes their gradient reads): dout then gets whole float4s (g, 0, 0, 0).
+template <typename LT>
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out, int so, const LT* __restrict__ label,
                                                    const long* __restrict__ uid, const float* __restrict__ delta,
                                                    long n_delta, float alpha, int B, int T, float* __restrict__ loss_sum,
-                                                   float* __restrict__ dout, float* __restrict__ ddelta, int* __restrict__ err) {
+                                                   float* __restrict__ dout, int sd, float* __restrict__ ddelta, int* __restrict__ err) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -199,8 +202,8 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int t = lane + 64 * v;
-        o[v] = t < T ? out[(long)b * T + t] : -3.0e38f;
-        y[v] = t < T ? label[(long)b * T + t] : 0.f;
+        o[v] = t < T ? out[((long)b * T + t) * so] : -3.0e38f;
+        y[v] = t < T ? (float)label[(long)b * T + t] : 0.f;
         mx = fmaxf(mx, o[v]);
     }
     mx = wave_max64(mx);
@@ -242,7 +245,10 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int t = lane + 64 * v;
-        if (t < T) dout[(long)b * T + t] = g[v];
+        if (t < T) {
+            if (sd == 4) *reinterpret_cast<f32x4*>(dout + ((long)b * T + t) * 4) = f32x4{g[v], 0.f, 0.f, 0.f};
+            else dout[((long)b * T + t) * sd] = g[v];
+        }
     }
     if (lane == 0) {
         atomicAdd(loss_sum, total * inv);
@@ -250,11 +256,16 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out
     }
 }
 
-hipError_t loss_launch(const float* out, const float* label, const long* uid, const float* delta, long n_delta, float alpha,
-                       int B, int T, float* loss_sum, float* dout, float* ddelta, int* err, hipStream_t st) {
+hipError_t loss_launch(const float* out, int out_stride, const void* label, int label_is_f64, const long* uid, const float* delta,
+                       long n_delta, float alpha, int B, int T, float* loss_sum, float* dout, int dout_stride, float* ddelta, int* err,
+                       hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(loss_kernel, dim3((B + 3) / 4), dim3(256), 0, st, out, label, uid, delta, n_delta, alpha, B, T, loss_sum, dout,
-                       ddelta, err);
+    if (label_is_f64)
+        hipLaunchKernelGGL(loss_kernel<double>, dim3((B + 3) / 4), dim3(256), 0, st, out, out_stride, (const double*)label, uid, delta,
+                           n_delta, alpha, B, T, loss_sum, dout, dout_stride, ddelta, err);
+    else
+        hipLaunchKernelGGL(loss_kernel<float>, dim3((B + 3) / 4), dim3(256), 0, st, out, out_stride, (const float*)label, uid, delta,
+                           n_delta, alpha, B, T, loss_sum, dout, dout_stride, ddelta, err);
     return hipGetLastError();
 }
 

@@ -7,8 +7,9 @@ hipError_t bmm_rows_launch(const float* W, long wsb, long wsi, long wsj, const f
                            float* out, long osb, int ldo, int B, int I, int J, int D, int accumulate, hipStream_t st);
 hipError_t rowdot_launch(const float* g, long gsb, int ldg, const float* h, long hsb, int ldh, float* ds,
                          int B, int T, int H, int D, float* zero_out, int zero_n, hipStream_t st);
-hipError_t loss_launch(const float* out, const float* label, const long* uid, const float* delta, long n_delta, float alpha,
-                       int B, int T, float* loss_sum, float* dout, float* ddelta, int* err, hipStream_t st);
+hipError_t loss_launch(const float* out, int out_stride, const void* label, int label_is_f64, const long* uid, const float* delta,
+                       long n_delta, float alpha, int B, int T, float* loss_sum, float* dout, int dout_stride, float* ddelta, int* err,
+                       hipStream_t st);
 hipError_t adam_launch(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                        float wd, int step, int zero_grad, hipStream_t st);
 hipError_t adam_dev_launch(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,

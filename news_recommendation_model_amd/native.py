@@ -49,7 +49,9 @@ SIGNATURES = {
     "nrm_concat_cols": (_c_i, [_c_fp, _c_fp, _c_fp, _c_i, _c_fp, _c_i, _c_l, _c_fp]),
     "nrm_pool_bmm": (_c_i, [_c_fp, _c_l, _c_l, _c_l, _c_fp, _c_i, _c_fp] + [_c_i] * 5 + [_c_fp]),
     "nrm_pool_rowdot": (_c_i, [_c_fp, _c_i, _c_fp, _c_fp] + [_c_i] * 4 + [_c_fp, _c_i, _c_fp]),
-    "nrm_loss_fwd_bwd": (_c_i, [_c_fp] * 4 + [_c_l, ctypes.c_float, _c_i, _c_i] + [_c_fp] * 5),
+    "nrm_small_linear_relu_fwd": (_c_i, [_c_fp, _c_i, _c_fp, _c_fp, _c_fp, _c_l, _c_i, _c_i, _c_i, _c_fp]),
+    "nrm_small_linear_relu_bwd": (_c_i, [_c_fp, _c_i, _c_fp, _c_fp, _c_fp, _c_i, _c_l, _c_i, _c_i, _c_fp, _c_fp]),
+    "nrm_loss_fwd_bwd": (_c_i, [_c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_fp, _c_l, ctypes.c_float, _c_i, _c_i, _c_fp, _c_fp, _c_i, _c_fp, _c_fp, _c_fp]),
     "nrm_adam_step": (_c_i, [_c_fp] * 4 + [_c_l] + [ctypes.c_float] * 5 + [_c_i, _c_i, _c_fp]),
     "nrm_adam_step_dev": (_c_i, [_c_fp] * 4 + [_c_l] + [ctypes.c_float] * 5 + [_c_fp, _c_i, _c_fp]),
     "nrm_gather_flat": (_c_i, [_c_fp, _c_fp, _c_fp, _c_i, _c_fp, _c_l, _c_fp]),

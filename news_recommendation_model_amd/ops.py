@@ -562,6 +562,30 @@ pwattn_bwd = _op("pwattn_bwd", "(Tensor ds, Tensor t, Tensor h, Tensor fc1_weigh
                  "bool need_dt, bool need_dh) -> (Tensor, Tensor, Tensor, Tensor, Tensor)", _pwattn_bwd_impl, _pwattn_bwd_fake)
 
 
+# The backward overwrites the saved [B,T,H,D] pre-activation in place (2.46 GB at C3: no second copy), so by default a graph
+# can be walked once.  set_retain_attention_graph(True) restores the reference's behaviour (autograd.grad(..., retain_graph=True),
+# a second backward): every backward then works on a COPY of z -- one extra [B,T,H,D] buffer and one copy per backward.
+_retain_attention_graph = False
+
+
+def set_retain_attention_graph(on=True):
+    global _retain_attention_graph
+    prev, _retain_attention_graph = _retain_attention_graph, bool(on)
+    return prev
+
+
+def _consume_z(ctx, z):
+    """The dz buffer of this backward: z itself (then the graph is spent) or, with set_retain_attention_graph, a copy."""
+    if _retain_attention_graph:
+        return z.detach().clone()
+    if ctx.consumed:
+        raise RuntimeError("pointwise attention: backward through this graph a second time is not supported "
+                           "(the saved pre-activation buffer was consumed by the first backward); re-run the forward "
+                           "instead of retain_graph=True, or call ops.set_retain_attention_graph(True) first")
+    ctx.consumed = True
+    return z.detach()
+
+
 def _pwattn_setup(ctx, inputs, output):
     t, h, w1, b1, w2, b2, save_z, mma = inputs
     s, z = output
@@ -580,16 +604,9 @@ def _pwattn_backward(ctx, ds, _dz):
     if not ctx.save_z:
         raise RuntimeError("pointwise attention: the forward ran with save_z=False (no-grad / inference call); there "
                            "is nothing to differentiate through")
-    if ctx.consumed:
-        # the saved pre-activation is overwritten in place by dz (2.46 GB at C3: no second copy), so the graph can be
-        # walked once; the reference's autograd would allow retain_graph=True here
-        raise RuntimeError("pointwise attention: backward through this graph a second time is not supported "
-                           "(the saved pre-activation buffer was consumed by the first backward); "
-                           "re-run the forward instead of retain_graph=True")
-    ctx.consumed = True
     t, h, w1, w2, z = ctx.saved_tensors
     need = ctx.needs_input_grad
-    dt, dh, dw1, db1, dw2b2 = pwattn_bwd(ds, t, h, w1, w2, z.detach(), ctx.mma, bool(need[0]), bool(need[1]))
+    dt, dh, dw1, db1, dw2b2 = pwattn_bwd(ds, t, h, w1, w2, _consume_z(ctx, z), ctx.mma, bool(need[0]), bool(need[1]))
     D = t.shape[2]
     return ((dt if need[0] else None), (dh if need[1] else None), dw1, db1, dw2b2[:D].reshape(ctx.w2_shape),
             dw2b2[D:D + 1].reshape(ctx.b2_shape), None, None)
@@ -701,6 +718,81 @@ def linear(x, weight, bias=None, gelu=False):
     _require_gpu(x, weight)
     y = linear_fwd(x.reshape(-1, x.shape[-1]), weight, bias, bool(gelu))[0]
     return y.reshape(*lead, weight.shape[0])
+
+
+# ReLU(Linear) with a handful of columns (the instant-interest layer): dedicated kernels instead of a zero-padded K = 4 GEMM
+SMALL_LINEAR_MAX_K, SMALL_LINEAR_MAX_N = 4, 8
+
+
+def _small_linear_relu_fwd_impl(x, weight, bias):
+    _require_gpu(x, weight)
+    N, K = weight.shape
+    if x.dtype not in (torch.float32, torch.float64):
+        x = x.to(torch.float32)
+    x = x.contiguous()
+    R = x.shape[0]
+    w, b = _f32c(weight), (_f32c(bias) if bias is not None else None)
+    y = torch.empty(R, _pad4(N), dtype=torch.float32, device=x.device)
+    native.call("nrm_small_linear_relu_fwd", native.ptr(x), 1 if x.dtype == torch.float64 else 0, native.ptr(w),
+                native.ptr(b) if b is not None else None, native.ptr(y), R, K, N, y.stride(0), native.stream_ptr())
+    return y[:, :N]
+
+
+small_linear_relu_fwd = _op("small_linear_relu_fwd", "(Tensor x, Tensor weight, Tensor? bias) -> Tensor", _small_linear_relu_fwd_impl,
+                            lambda x, weight, bias: _padded_empty(x, x.shape[0], weight.shape[0]))
+
+
+def _small_linear_relu_bwd_impl(dy, x, weight, bias):
+    """-> [N*K + N] floats: d weight (row-major) followed by d bias."""
+    _require_gpu(dy, x, weight)
+    N, K = weight.shape
+    if x.dtype not in (torch.float32, torch.float64):
+        x = x.to(torch.float32)
+    x = x.contiguous()
+    w, b = _f32c(weight), (_f32c(bias) if bias is not None else None)
+    if not (dy.dtype == torch.float32 and dy.dim() == 2 and dy.stride(1) == 1 and dy.stride(0) >= N):
+        dy = _f32c(dy)                                 # (a column block of the head gradient is read in place)
+    dwb = torch.zeros(N * K + N, dtype=torch.float32, device=x.device)
+    native.call("nrm_small_linear_relu_bwd", native.ptr(x), 1 if x.dtype == torch.float64 else 0, native.ptr(w),
+                native.ptr(b) if b is not None else None, native.ptr(dy), dy.stride(0) if dy.shape[0] > 1 else N, x.shape[0], K, N,
+                native.ptr(dwb), native.stream_ptr())
+    return dwb
+
+
+small_linear_relu_bwd = _op("small_linear_relu_bwd", "(Tensor dy, Tensor x, Tensor weight, Tensor? bias) -> Tensor", _small_linear_relu_bwd_impl,
+                            lambda dy, x, weight, bias: x.new_empty((weight.numel() + weight.shape[0],), dtype=torch.float32))
+
+
+def _small_linear_setup(ctx, inputs, output):
+    ctx.set_materialize_grads(False)
+    ctx.has_bias = inputs[2] is not None
+    ctx.save_for_backward(*[t for t in inputs if t is not None])
+
+
+def _small_linear_backward(ctx, dy):
+    if dy is None:
+        return None, None, None
+    x, weight, *rest = ctx.saved_tensors
+    if ctx.needs_input_grad[0]:
+        raise RuntimeError("small_linear_relu: the input has no gradient path (raw popularity scalars); use ops.linear + relu")
+    dwb = small_linear_relu_bwd(dy, x, weight, rest[0] if rest else None)
+    n = weight.numel()
+    return None, dwb[:n].view(weight.shape), (dwb[n:] if ctx.has_bias else None)
+
+
+torch.library.register_autograd("nrm::small_linear_relu_fwd", _small_linear_backward, setup_context=_small_linear_setup, lib=_LIB)
+
+
+def small_linear_relu(x, weight, bias=None):
+    """relu(nn.Linear(x)) on the last dimension for K <= 4 inputs, N <= 8 outputs and an input without a gradient; other
+    shapes go through ops.linear + relu."""
+    N, K = weight.shape
+    if (K > SMALL_LINEAR_MAX_K or N > SMALL_LINEAR_MAX_N or x.requires_grad or x.numel() == 0 or x.shape[-1] != K):
+        return torch.relu(linear(x if x.dtype == torch.float32 else x.to(torch.float32), weight, bias))
+    _require_gpu(x, weight)
+    lead = x.shape[:-1]
+    y = small_linear_relu_fwd(x.reshape(-1, K), weight, bias)
+    return y.reshape(*lead, N) if y.is_contiguous() else y.unflatten(0, tuple(lead))
 
 
 def _mlp_gelu_fwd_impl(x, w1, b1, w2, b2, mul):
@@ -1193,14 +1285,9 @@ def _attend_pool_backward(ctx, g, _ds, _dz):
     if not ctx.save_z:
         raise RuntimeError("pointwise attention: the forward ran with save_z=False (no-grad / inference call); there "
                            "is nothing to differentiate through")
-    if ctx.consumed:
-        raise RuntimeError("pointwise attention: backward through this graph a second time is not supported "
-                           "(the saved pre-activation buffer was consumed by the first backward); "
-                           "re-run the forward instead of retain_graph=True")
-    ctx.consumed = True
     t, h, w1, w2, s, z = ctx.saved_tensors
     need = ctx.needs_input_grad
-    dt, dh, dw1, db1, dw2b2 = attend_pool_bwd(g, t, h, w1, w2, s, z.detach(), ctx.mma, bool(need[0]), bool(need[1]))
+    dt, dh, dw1, db1, dw2b2 = attend_pool_bwd(g, t, h, w1, w2, s, _consume_z(ctx, z), ctx.mma, bool(need[0]), bool(need[1]))
     D = t.shape[2]
     return ((dt if need[0] else None), (dh if need[1] else None), dw1, db1, dw2b2[:D].reshape(ctx.w2_shape),
             dw2b2[D:D + 1].reshape(ctx.b2_shape), None, None)
@@ -1270,24 +1357,31 @@ def check_index_errors(device="cuda"):
 
 def _loss_impl(out, delta, label, user_id, alpha):
     """The two-term BCE-on-softmax loss of reference models/user_model.py:37-43, value and gradients in one
-    kernel (one wave per impression)."""
+    kernel (one wave per impression).  Returns (loss, dout, ddelta); dout [B,T] = dL/dout is column 0 of a zero-padded
+    [B*T, 4] matrix -- the layout the GEMM that consumes it streams, so nothing re-pads it."""
     _require_gpu(out, delta, label, user_id)
     B, T = out.shape
-    o, y, d = _f32c(out), _f32c(label), _f32c(delta)
+    d = _f32c(delta)
+    # the logits arrive as column 0 of the padded [B*T, 4] output of the last GEMM (strides (4T, 4)): read in place
+    so = out.stride(1) if T > 1 else (out.stride(0) if B > 1 else 1)
+    if not (out.dtype == torch.float32 and so >= 1 and (T == 1 or out.stride(1) == so) and (B == 1 or out.stride(0) == T * so)):
+        out, so = _f32c(out), 1
+    y = label if (label.dtype in (torch.float32, torch.float64) and label.is_contiguous()) else _f32c(label)
     uid = user_id.to(torch.int64).contiguous()
-    loss = torch.zeros(1, dtype=torch.float32, device=out.device)
-    dout = torch.empty(B, T, dtype=torch.float32, device=out.device)
+    loss = torch.zeros((), dtype=torch.float32, device=out.device)
     ddelta = torch.zeros_like(d)
-    native.call("nrm_loss_fwd_bwd", native.ptr(o), native.ptr(y), native.ptr(uid), native.ptr(d), d.numel(), float(alpha),
-                B, T, native.ptr(loss), native.ptr(dout), native.ptr(ddelta), native.ptr(index_error_flag(out.device)),
-                native.stream_ptr())
-    return loss.reshape(()), dout, ddelta
+    dbuf = torch.empty(B * T, 4, dtype=torch.float32, device=out.device)
+    native.call("nrm_loss_fwd_bwd", native.ptr(out), so, native.ptr(y), 1 if y.dtype == torch.float64 else 0, native.ptr(uid),
+                native.ptr(d), d.numel(), float(alpha), B, T, native.ptr(loss), native.ptr(dbuf), 4, native.ptr(ddelta),
+                native.ptr(index_error_flag(out.device)), native.stream_ptr())
+    return loss, dbuf[:, 0].view(B, T), ddelta
 
 
 softmax_bce_loss_op = _op("softmax_bce_loss", "(Tensor out, Tensor delta, Tensor label, Tensor user_id, float alpha) -> "
                           "(Tensor, Tensor, Tensor)", _loss_impl,
                           lambda out, delta, label, user_id, alpha: (out.new_empty((), dtype=torch.float32),
-                                                                     out.new_empty(tuple(out.shape), dtype=torch.float32),
+                                                                     out.new_empty((out.shape[0] * out.shape[1], 4), dtype=torch.float32)[:, 0]
+                                                                     .view(out.shape[0], out.shape[1]),
                                                                      delta.new_empty(tuple(delta.shape), dtype=torch.float32)))
 
 
@@ -1296,10 +1390,30 @@ def _loss_setup(ctx, inputs, output):
     ctx.save_for_backward(output[1], output[2])
 
 
+# The gradient train_step seeds the backward with: a cached scalar 1.  The loss backward recognises it (by address) and hands
+# its saved dL/dout and dL/ddelta on as they are -- no ones_like fill by autograd, no two multiplies by one.
+_unit_grads = {}
+
+
+def unit_grad(like):
+    key = like.device.index if like.device.index is not None else torch.cuda.current_device()
+    u = _unit_grads.get(key)
+    if u is None:
+        u = _unit_grads[key] = torch.ones((), dtype=torch.float32, device=like.device)
+    return u
+
+
 def _loss_backward(ctx, gl, _a, _b):
     if gl is None:
         return None, None, None, None, None
     dout, ddelta = ctx.saved_tensors
+    u = _unit_grads.get(dout.device.index)
+    try:
+        unit = u is not None and gl.dim() == 0 and gl.data_ptr() == u.data_ptr()
+    except RuntimeError:                                  # fake / functional tensors (tracing) have no address: the general formula
+        unit = False
+    if unit:
+        return dout, ddelta, None, None, None
     return dout * gl, ddelta * gl, None, None, None
 
 
@@ -1535,7 +1649,7 @@ adam_step = _op("adam_step", "(Tensor(a!) param, Tensor(b!) grad, Tensor(c!) exp
                 "float lr, float beta1, float beta2, float eps, float weight_decay, bool zero_grad) -> ()",
                 _adam_step_impl, lambda *a: None)
 
-OPS = ("pwattn_fwd", "pwattn_bwd", "linear_fwd", "linear_bwd", "mlp_gelu_fwd", "mlp_gelu_bwd", "batch_norm_stats", "batch_norm_apply",
+OPS = ("pwattn_fwd", "pwattn_bwd", "linear_fwd", "linear_bwd", "small_linear_relu_fwd", "small_linear_relu_bwd", "mlp_gelu_fwd", "mlp_gelu_bwd", "batch_norm_stats", "batch_norm_apply",
        "batch_norm_bwd", "gate_block_fwd", "gate_block_bwd", "concat_cols",
        "weighted_pool_fwd", "weighted_pool_bwd", "attend_pool_fwd", "attend_pool_bwd", "softmax_bce_loss", "frontend_fwd", "frontend_bwd",
        "frontend_pair_fwd", "frontend_pair_bwd", "row_auc", "adam_step")

@@ -258,11 +258,12 @@ def train_step(model, optimizer, batch, reducer: FlatGradReducer | None = None, 
         # gradient) are recorded during backward and run as ONE launch when FlatAdam gathers the gradients.  A gradient that
         # exists already would be accumulated into before its reduction ran: then (and on request) reductions run at once.
         defer = defer_reductions and all(p.grad is None for p in optimizer.params)
+        seed = ops.unit_grad(loss) if loss.dim() == 0 and loss.dtype == torch.float32 else None     # (see ops.unit_grad)
         if defer:
             with ops.deferred_slab_reductions():
-                loss.backward()
+                loss.backward(seed)
         else:
-            loss.backward()
+            loss.backward(seed)
         optimizer.all_reduce_grads()
         optimizer.step(zero_grad=True)                # Adam + zero_grad fused in one launch
     else:

@@ -52,7 +52,12 @@ def test_train_step_matches_reference_fixture(lib, name):
         if k in ZERO_GRAD_KEYS:
             assert np.abs(got).max() < 1e-5 * max(1.0, gscale), k
         else:
-            assert np.abs(got - ref).max() <= GRAD_TOL * np.abs(ref).max() + 1e-9, k
+            # The instant-interest layer's gradients are column sums of the head gradient over the batch.  The BatchNorm part of
+            # that gradient sums to ZERO over the batch in exact arithmetic, and the near-constant popularity features (column
+            # variance ~1e-5, rstd ~300) make its individual terms hundreds of times larger than the sum that survives: what
+            # is compared here is a cancellation residue, a few 1e-5 of the model's gradient scale on CPU and GPU alike.
+            floor = 1e-4 * gscale if k.startswith("instant_interest_model.") else 0.0
+            assert np.abs(got - ref).max() <= GRAD_TOL * np.abs(ref).max() + floor + 1e-9, (k, gscale)
     opt.step()
     opt.zero_grad()
     torch.cuda.synchronize()
@@ -275,7 +280,12 @@ def test_random_models_match_oracle(lib, emb, B, H, T, pad_h, pad_t, mma):
         if k in ZERO_GRAD_KEYS:
             assert np.abs(got).max() < 1e-5 * max(1.0, gscale), k
         else:
-            assert np.abs(got - ref).max() <= GRAD_TOL * np.abs(ref).max() + 1e-9, k
+            # The instant-interest layer's gradients are column sums of the head gradient over the batch.  The BatchNorm part of
+            # that gradient sums to ZERO over the batch in exact arithmetic, and the near-constant popularity features (column
+            # variance ~1e-5, rstd ~300) make its individual terms hundreds of times larger than the sum that survives: what
+            # is compared here is a cancellation residue, a few 1e-5 of the model's gradient scale on CPU and GPU alike.
+            floor = 1e-4 * gscale if k.startswith("instant_interest_model.") else 0.0
+            assert np.abs(got - ref).max() <= GRAD_TOL * np.abs(ref).max() + floor + 1e-9, (k, gscale)
 
 
 @pytest.mark.parametrize("name", TRAJ_CASES)
@@ -327,6 +337,16 @@ def test_second_backward_through_attention_raises(lib):
     with torch.no_grad():                                       # no [B,T,H,D] buffer is kept without grad mode
         s3 = ops.pointwise_attention_scores(t, h, w1, b1, w2, b2)
     assert not s3.requires_grad and torch.allclose(s3, s2.detach(), rtol=1e-6, atol=1e-6)
+    # the reference's behaviour on request: every backward works on a copy of the saved pre-activation
+    prev = ops.set_retain_attention_graph(True)
+    try:
+        for f in (lambda: ops.pointwise_attention_scores(t, h, w1, b1, w2, b2), lambda: ops.attend_and_pool(t, h, w1, b1, w2, b2)):
+            out = f()
+            ga = torch.autograd.grad(out.sum(), [t, h], retain_graph=True)
+            gb = torch.autograd.grad(out.sum(), [t, h])
+            assert all(torch.equal(a, b) for a, b in zip(ga, gb))
+    finally:
+        ops.set_retain_attention_graph(prev)
 
 
 def test_loss_user_ids_negative_wrap_and_out_of_range_flag(lib):

@@ -174,6 +174,62 @@ def test_attention_backward_skips_gradients_nobody_asked_for(lib, mma, need):
             assert float((a - b).abs().max()) <= 2e-5 * (float(b.abs().max()) + 1e-30), name
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("R,K,N", [(7, 3, 8), (3840, 3, 8), (1000, 4, 5), (65, 1, 1)])
+def test_small_linear_relu_matches_torch(lib, R, K, N, dtype):
+    """The instant-interest layer ReLU(Linear(3 -> 8)) as its own pair of kernels (reads float32 or the DataLoader's float64
+    rows; the upstream gradient may be a column block of a wider matrix)."""
+    from news_recommendation_model_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(R + K + N)
+    x = torch.randn(R, K, device="cuda", generator=g).to(dtype)
+    w = torch.randn(N, K, device="cuda", generator=g).requires_grad_(True)
+    b = torch.randn(N, device="cuda", generator=g).requires_grad_(True)
+    wide = torch.randn(R, N + 12, device="cuda", generator=g)
+    y = ops.small_linear_relu(x, w, b)
+    y.backward(wide[:, 4:4 + N])
+    wr, br = w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    yr = torch.relu(torch.nn.functional.linear(x.float().double(), wr, br))
+    yr.backward(wide[:, 4:4 + N].double())
+    assert torch.allclose(y.detach().double(), yr.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(w.grad.double(), wr.grad, rtol=1e-4, atol=1e-4 * float(wr.grad.abs().max()))
+    assert torch.allclose(b.grad.double(), br.grad, rtol=1e-4, atol=1e-4 * float(br.grad.abs().max()))
+    if dtype == torch.float32:
+        _opcheck(torch.ops.nrm.small_linear_relu_fwd.default, (x, w, b))
+    # shapes outside the small kernels fall back to linear + relu
+    w9 = torch.randn(9, K, device="cuda", generator=g)
+    assert torch.allclose(ops.small_linear_relu(x.float(), w9), torch.relu(torch.nn.functional.linear(x.float(), w9)), rtol=1e-5, atol=1e-5)
+
+
+def test_loss_reads_strided_logits_and_float64_labels_and_passes_unit_gradients_through(lib):
+    """The loss op reads the logits in place as column 0 of the padded [B*T, 4] GEMM output, takes the DataLoader's float64
+    labels, writes dL/dout into the same padded layout, and -- seeded with ops.unit_grad -- hands its saved gradients on
+    without multiplying them by one."""
+    from news_recommendation_model_amd import ops
+    B, T = 6, 9
+    g = torch.Generator(device="cuda").manual_seed(11)
+    buf = torch.randn(B * T, 4, device="cuda", generator=g)
+    out_strided = buf[:, 0].view(B, T).requires_grad_(True)
+    out_dense = out_strided.detach().contiguous().requires_grad_(True)
+    delta = (0.1 * torch.randn(5, device="cuda", generator=g))
+    label = torch.zeros(B, T, device="cuda", dtype=torch.float64)
+    label[torch.arange(B), torch.arange(B)] = 1
+    uid = torch.tensor([0, 1, 4, 2, 2, 3], device="cuda")
+    res = []
+    for out, y, seed in ((out_strided, label, True), (out_dense, label.float(), False)):
+        d = delta.clone().requires_grad_(True)
+        loss = ops.softmax_bce_loss(out, d, y, uid, 0.95)
+        (gout, gd) = torch.autograd.grad(loss, [out, d], grad_outputs=ops.unit_grad(loss) if seed else None)
+        res.append((loss.detach(), gout, gd))
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-6, atol=0)          # (the loss is summed with float atomics: order varies)
+    assert torch.equal(res[0][1], res[1][1]) and torch.allclose(res[0][2], res[1][2], rtol=1e-6, atol=1e-9)
+    assert res[0][1].stride() == (4 * T, 4)                 # the padded layout the consuming GEMM streams
+    # a non-unit upstream gradient still scales
+    d = delta.clone().requires_grad_(True)
+    loss = ops.softmax_bce_loss(out_dense, d, label, uid, 0.95)
+    (g3,) = torch.autograd.grad(loss * 3.0, [d])
+    assert torch.allclose(g3, 3.0 * res[1][2], rtol=1e-6, atol=1e-9)
+
+
 def test_ops_called_through_torch_ops_match_the_python_entry_points(lib):
     from news_recommendation_model_amd import ops
     t, h, w1, b1, w2, b2 = _attn_args(grad=False)
