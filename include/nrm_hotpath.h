@@ -246,12 +246,22 @@ int nrm_frontend_fwd(const void* x, int x_is_f64, int nrows, int xcols, int P, i
                      const float* year_tab, const float* month_tab, const float* day_tab, const float* hour_tab,
                      int n_year, int n_month, int n_day, int n_hour, int e3,
                      float* lab, int ldlab, float* ti, int ldti, int* err, nrm_stream_t stream);
-/* backward of the label rows: accumulates (+=, float atomics) the table / sentiment-layer gradients */
+/* backward of the label rows: accumulates (+=, float atomics) the table / sentiment-layer gradients.  d_cat_tab may be NULL:
+ * the category-table gradient is then left to nrm_frontend_cat_grad */
 int nrm_frontend_bwd(const void* x, int x_is_f64, int nrows, int xcols, int P, int n_sub, int behaviour,
                      const float* dlab, int lddl, const float* sen_w, const float* sen_b,
                      int n_cat, int e0, int e1, int n_type, int e2, int n_year, int n_month, int n_day, int n_hour, int e3,
                      float* d_cat_tab, float* d_sen_w, float* d_sen_b, float* d_type_tab,
                      float* d_year_tab, float* d_month_tab, float* d_day_tab, float* d_hour_tab, nrm_stream_t stream);
+
+/* category-table gradient of up to two row sets (history rows, candidate rows; nrows = 0 skips one) by a counting sort of the
+ * (row, slot) references by category id and a gather-sum over runs of equal ids -- instead of (1 + n_sub) * e0 float atomics per
+ * row.  d_cat_tab [n_cat, e0] is accumulated into (+=).  ws: nrm_frontend_cat_ws_ints(n_cat, nrows0 + nrows1, n_sub) int32 of
+ * scratch.  Both row sets have the same element type (x_is_f64).  Summation order inside an id varies from run to run. */
+long nrm_frontend_cat_ws_ints(int n_cat, long nrows_total, int n_sub);
+int nrm_frontend_cat_grad(const void* x0, int nrows0, int xcols0, const float* dlab0, int lddl0,
+                          const void* x1, int nrows1, int xcols1, const float* dlab1, int lddl1, int x_is_f64,
+                          int P, int n_sub, int n_cat, int e0, float* d_cat_tab, int* ws, nrm_stream_t stream);
 
 /* ---- per-impression ROC-AUC and top-1 hit (reference train.py:77-80, verify.py:25-36, tool/evaluation.py:3-5;
  * sklearn roc_auc_score for binary labels = Mann-Whitney U with ties counted 1/2).  score, label [B,T]; len [B]

@@ -521,7 +521,7 @@ int nrm_frontend_bwd(const void* x, int x_is_f64, int nrows, int xcols, int P, i
                      float* d_cat_tab, float* d_sen_w, float* d_sen_b, float* d_type_tab,
                      float* d_year_tab, float* d_month_tab, float* d_day_tab, float* d_hour_tab, nrm_stream_t stream) {
     if (int rc = check_fe("nrm_frontend_bwd", nrows, xcols, P, n_sub, behaviour, e0, e1, e2, e3)) return rc;
-    if (!x || !dlab || !sen_w || !sen_b || !d_cat_tab || !d_sen_w || !d_sen_b || !d_type_tab || !d_year_tab || !d_month_tab || !d_day_tab || !d_hour_tab)
+    if (!x || !dlab || !sen_w || !sen_b || !d_sen_w || !d_sen_b || !d_type_tab || !d_year_tab || !d_month_tab || !d_day_tab || !d_hour_tab)
         return fail(NRM_EINVAL, "nrm_frontend_bwd: null pointer");
     if (lddl < e0 + e1 + e2 + e3) return fail(NRM_EINVAL, "nrm_frontend_bwd: lddl=%d too small", lddl);
     nrm::FrontendParams p = {};
@@ -531,6 +531,23 @@ int nrm_frontend_bwd(const void* x, int x_is_f64, int nrows, int xcols, int P, i
     p.n_cat = n_cat; p.n_type = n_type; p.n_year = n_year; p.n_month = n_month; p.n_day = n_day; p.n_hour = n_hour;
     p.e0 = e0; p.e1 = e1; p.e2 = e2; p.e3 = e3; p.P = P; p.n_sub = n_sub; p.xcols = xcols; p.behaviour = behaviour;
     return check_hip(nrm::frontend_bwd_launch(p, x, x_is_f64, dlab, lddl, nrows, (hipStream_t)stream), "frontend_bwd");
+}
+
+long nrm_frontend_cat_ws_ints(int n_cat, long nrows_total, int n_sub) {
+    if (n_cat <= 0 || nrows_total < 0 || n_sub < 0) return 0;
+    return nrm::cat_grad_ws_ints(n_cat, nrows_total, n_sub);
+}
+
+int nrm_frontend_cat_grad(const void* x0, int nrows0, int xcols0, const float* dlab0, int lddl0,
+                          const void* x1, int nrows1, int xcols1, const float* dlab1, int lddl1, int x_is_f64,
+                          int P, int n_sub, int n_cat, int e0, float* d_cat_tab, int* ws, nrm_stream_t stream) {
+    if (nrows0 < 0 || nrows1 < 0 || P <= 0 || n_sub < 1 || n_sub > 16 || n_cat <= 0 || e0 <= 0 || e0 > 512)
+        return fail(NRM_EINVAL, "nrm_frontend_cat_grad: nrows=%d,%d P=%d n_sub=%d n_cat=%d e0=%d (1 <= n_sub <= 16, e0 <= 512)", nrows0, nrows1, P, n_sub, n_cat, e0);
+    if ((nrows0 > 0 && (!x0 || !dlab0 || lddl0 < e0 || xcols0 < 4 + P + 1 + n_sub)) || (nrows1 > 0 && (!x1 || !dlab1 || lddl1 < e0 || xcols1 < 4 + P + 1 + n_sub)) || !d_cat_tab || !ws)
+        return fail(NRM_EINVAL, "nrm_frontend_cat_grad: null pointer, lddl < e0 or packed rows too short");
+    if (((long)nrows0 + nrows1) * (n_sub + 1) >= (1L << 31)) return fail(NRM_EINVAL, "nrm_frontend_cat_grad: more than 2^31 table references");
+    return check_hip(nrm::cat_grad_launch(x0, nrows0, xcols0, dlab0, lddl0, x1, nrows1, xcols1, dlab1, lddl1, x_is_f64, P, n_sub, n_cat, e0,
+                                          d_cat_tab, ws, (hipStream_t)stream), "frontend_cat_grad");
 }
 
 }  // extern "C"

@@ -18,4 +18,8 @@ struct FrontendParams {
 hipError_t frontend_fwd_launch(const FrontendParams& p, const void* x, int x_is_f64, int nrows, hipStream_t st);
 hipError_t frontend_bwd_launch(const FrontendParams& p, const void* x, int x_is_f64, const float* dlab, int lddl,
                                int nrows, hipStream_t st);
+long cat_grad_ws_ints(int n_cat, long nrows_total, int n_sub);
+hipError_t cat_grad_launch(const void* x0, int nrows0, int xcols0, const float* dlab0, int lddl0,
+                           const void* x1, int nrows1, int xcols1, const float* dlab1, int lddl1, int x_is_f64,
+                           int P, int n_sub, int n_cat, int e0, float* d_cat, int* ws, hipStream_t st);
 }  // namespace nrm

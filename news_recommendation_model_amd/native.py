@@ -59,6 +59,8 @@ SIGNATURES = {
     "nrm_frontend_fwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,  _c_fp, _c_i, _c_i,  _c_fp, _c_fp, _c_i,
                                  _c_fp, _c_i, _c_i,  _c_fp, _c_fp, _c_fp, _c_fp,  _c_i, _c_i, _c_i, _c_i, _c_i,
                                  _c_fp, _c_i, _c_fp, _c_i, _c_fp, _c_fp]),
+    "nrm_frontend_cat_ws_ints": (_c_l, [_c_i, _c_l, _c_i]),
+    "nrm_frontend_cat_grad": (_c_i, [_c_fp, _c_i, _c_i, _c_fp, _c_i] * 2 + [_c_i] * 5 + [_c_fp, _c_fp, _c_fp]),
     "nrm_frontend_bwd": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,  _c_fp, _c_i, _c_fp, _c_fp]
                          + [_c_i] * 10 + [_c_fp] * 8 + [_c_fp]),
 }

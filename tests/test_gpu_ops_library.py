@@ -174,6 +174,40 @@ def test_attention_backward_skips_gradients_nobody_asked_for(lib, mma, need):
             assert float((a - b).abs().max()) <= 2e-5 * (float(b.abs().max()) + 1e-30), name
 
 
+@pytest.mark.parametrize("emb,B,H,T", [(16, 3, 4, 2), (64, 9, 37, 5), (400, 4, 50, 30)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_category_gradient_by_counting_sort_matches_the_atomic_scatter(lib, monkeypatch, emb, B, H, T, dtype):
+    """The category-table gradient has two implementations: one float atomic per (reference, column) inside the front-end
+    backward, and (big batches) a counting sort of the references by category id + a gather-sum over runs.  Forced either way
+    on the same inputs they agree to summation order; so do the other seven table gradients (which the sort does not touch)."""
+    from news_recommendation_model_amd import config, ops, synth
+    dims = config.Dims.for_emb(emb, 40)
+    batch = synth.make_batch(dims, B, H, T, seed=emb + B, user_num=5, dtype=dtype)
+    sd = synth.make_state_dict(dims, seed=2, user_num=5)
+    inv = "invariant_interest_model."
+    keys = ("category_embedding.0.weight", "sentiment_embedding.0.weight", "sentiment_embedding.0.bias", "type_embedding.0.weight",
+            "year_embedding.0.weight", "month_embedding.0.weight", "day_embedding.0.weight", "hour_embedding.0.weight")
+    xh, xt = torch.from_numpy(batch["x_history"]).cuda(), torch.from_numpy(batch["x_target"]).cuda()
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("NRM_FE_SORT", mode)
+        tabs = [torch.from_numpy(sd[inv + k]).cuda().requires_grad_(True) for k in keys]
+        lab_h, _, lab_t, _ = ops.frontend_pair(xh, xt, dims.n_subcat, dims.pca_vector, *tabs)
+        if mode == "0":
+            gh, gt = torch.randn(lab_h.shape, device="cuda", generator=gen), torch.randn(lab_t.shape, device="cuda", generator=gen)
+        torch.autograd.backward([lab_h, lab_t], [gh, gt])
+        res[mode] = [t_.grad for t_ in tabs]
+        # one row set alone (the single-set op) through both implementations too
+        tabs1 = [torch.from_numpy(sd[inv + k]).cuda().requires_grad_(True) for k in keys]
+        lab1, _ = ops.frontend(xh, True, dims.n_subcat, dims.pca_vector, *tabs1)
+        lab1.backward(gh)
+        res[mode + "h"] = [t_.grad for t_ in tabs1]
+    for a, b in zip(res["0"] + res["0h"], res["1"] + res["1h"]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(a.abs().max()) + 1e-12)
+    assert float(res["1"][0].abs().max()) > 0
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("R,K,N", [(7, 3, 8), (3840, 3, 8), (1000, 4, 5), (65, 1, 1)])
 def test_small_linear_relu_matches_torch(lib, R, K, N, dtype):
