@@ -540,7 +540,7 @@ def _attn_bwd_core(ds, t, h, w1, w2, z, mma, need_dt=True, need_dh=True, acc=Non
         # two launches: (b,t)-grouped -> dt + dW_p slabs, (b,h)-grouped -> dh (issued separately so that
         # bench.py can time each kernel with its own event pair); the second one only when the history wants a gradient
         # (without a target gradient the first one runs without its dt epilogue: passes = 4)
-        for passes, tag in ((1 if need_dt else 4, "pwattn_bwd_e_bt"), (2, "pwattn_bwd_e_bh")):
+        for passes, tag in ((1, "pwattn_bwd_e_bt") if need_dt else (4, "pwattn_bwd_e_dw"), (2, "pwattn_bwd_e_bh")):
             if passes == 2 and not need_dh:
                 continue
             native.call("nrm_pwattn_bwd_contract", native.ptr(dz), native.ptr(t), native.ptr(h),
