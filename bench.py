@@ -320,8 +320,11 @@ def main_infer(args):
     model = trainer.build_model(dims, user_num, sd, device=dev, attention_mma=args.dtype).eval()
     batch = synth.make_batch(dims, B, H, T, seed=0, user_num=user_num, dtype=np.float32)
     tb = trainer.batch_to_device(batch, dev)
-    tb["empty_num"] = torch.zeros(B, dtype=torch.int64, device=dev)          # throughput run: no padded candidates
+    # throughput run: no padded candidates; on the host, where the reference's DataLoader leaves it (test.py:46) -- predict()
+    # reads the common-padding trim there without a device synchronisation
+    tb["empty_num"] = torch.zeros(B, dtype=torch.int64).pin_memory()
     models = [model]
+    run = evaluation.GraphedPredict(models) if args.graph else (lambda b: evaluation.predict(models, b))
     for _ in range(max(args.warmup, 2)):
         scores, live = evaluation.predict(models, tb)
     torch.cuda.synchronize()
@@ -333,9 +336,12 @@ def main_infer(args):
     torch.cuda.synchronize()
     inv.two_streams = None
     events, native.kernel_events = native.kernel_events, None
+    for _ in range(2):
+        scores, live = run(tb)                          # (graph mode: capture happens here, outside the timed region)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        scores, live = evaluation.predict(models, tb)
+        scores, live = run(tb)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     _ops.check_index_errors(dev)
@@ -364,7 +370,7 @@ def main_infer(args):
     line = {"metric": "inference impressions/sec (reference test.py:31-74 model_test, one model)", "value": round(B * args.steps / elapsed, 2),
             "unit": "impressions/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": args.workload, "mode": "infer", "batch": B, "hist": H, "candidates": T, "emb": D, "launch": "eager",
+            "config": {"workload": args.workload, "mode": "infer", "batch": B, "hist": H, "candidates": T, "emb": D, "launch": "hipGraph replay (evaluation.GraphedPredict)" if args.graph else "eager",
                        "attention_streams": 2 if inv.uses_two_streams(B * T * H * D) else 1,
                        "kernel_durations_from": "3 extra one-stream batches after the warm-up",
                        "step": "evaluation.predict: trim + eval-mode forward (no saved z) + softmax + de-padding softmax"},

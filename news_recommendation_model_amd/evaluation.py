@@ -23,8 +23,11 @@ def predict(models, batch):
     x_target, x_global and empty_num (trailing all-padding candidates per row)."""
     xh, xt, xg = batch["x_history"], batch["x_target"], batch["x_global"]
     ops._require_gpu(xh, xt, xg)
-    empty = batch["empty_num"].to(xt.device).to(torch.int64)
-    trim = int(empty.min()) if empty.numel() else 0
+    # the common-padding trim is a HOST decision (it changes T): taken from the tensor where it lives, so a DataLoader's CPU
+    # tensor costs no device synchronisation and the host keeps launching ahead of the GPU (a device tensor forces one per batch)
+    e_in = batch["empty_num"]
+    trim = int(e_in.min()) if e_in.numel() else 0
+    empty = e_in.to(xt.device, non_blocking=True).to(torch.int64)
     if trim > 0:                                              # test.py:48-56
         xt, xg = xt[:, :-trim], xg[:, :-trim]
         empty = empty - trim
@@ -43,6 +46,72 @@ def predict(models, batch):
     again = torch.softmax(out.masked_fill(~mask, float("-inf")), dim=1)
     scores = torch.where(padded, again, out)
     return scores, live
+
+
+class GraphedPredict:
+    """predict() captured into one HIP graph per (input shapes, common-padding trim) and replayed: the reference's test batches
+    (80 impressions, test.py:46) are launch-bound when stepped eagerly -- ~0.9 ms of host work for ~0.35 ms of kernels.  Inputs
+    are copied into static device buffers (from host or device tensors), the graph is replayed, and the returned ``scores`` /
+    ``live`` are the graph's static outputs: valid until the next call with the same key (clone them to keep them).
+    At most ``max_graphs`` graphs are kept (least recently used first out)."""
+
+    def __init__(self, models, max_graphs=16):
+        self.models = list(models)
+        self.max_graphs = max_graphs
+        self.graphs = {}
+
+    @torch.no_grad()
+    def __call__(self, batch):
+        from . import native
+        if native.kernel_events is not None:
+            raise RuntimeError("per-kernel event timing cannot be recorded inside a graph capture")
+        dev = next(self.models[0].parameters()).device
+        e_in = batch["empty_num"]
+        trim = int(e_in.min()) if e_in.numel() else 0                 # host decision, as in predict()
+        names = ("x_history", "x_target", "x_global", "empty_num")
+        key = tuple((tuple(batch[k].shape), batch[k].dtype) for k in names) + (trim,)
+        ent = self.graphs.pop(key, None)
+        if ent is None:
+            static = {k: torch.empty(batch[k].shape, dtype=batch[k].dtype, device=dev) for k in names}
+            for k in names:
+                static[k].copy_(batch[k], non_blocking=True)
+            host_empty = torch.full_like(e_in, trim, device="cpu")   # what predict() reads on the host: only its minimum matters
+            feed = dict(static, empty_num=_HostMin(static["empty_num"], host_empty))
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):                             # allocator / packed-weight warm-up outside the capture
+                for _ in range(2):
+                    predict(self.models, feed)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                scores, live = predict(self.models, feed)
+            ent = (graph, static, scores, live)
+            while len(self.graphs) >= self.max_graphs:
+                self.graphs.pop(next(iter(self.graphs)))
+        else:
+            for k in names:
+                ent[1][k].copy_(batch[k], non_blocking=True)
+        self.graphs[key] = ent                                        # (re-inserted last: most recently used)
+        ent[0].replay()
+        return ent[2], ent[3]
+
+
+class _HostMin:
+    """empty_num for a captured predict(): .min() / .numel() answer from a host tensor (no synchronisation, nothing captured),
+    .to(device) hands over the static device buffer."""
+
+    def __init__(self, device_tensor, host_tensor):
+        self.dev, self.host = device_tensor, host_tensor
+
+    def numel(self):
+        return self.host.numel()
+
+    def min(self):
+        return self.host.min()
+
+    def to(self, *args, **kwargs):
+        return self.dev
 
 
 def row_auc_top1(scores, labels, live=None):

@@ -56,6 +56,19 @@ def test_predict_follows_test_py_semantics(lib):
         assert int(live[b]) == len(r)
         assert rel_err(scores[b, :len(r)].cpu().numpy(), r) < 1e-3
     assert evaluation.rank_row([0.1, 0.7, 0.2]) == [3, 1, 2]
+    # the same call captured into a HIP graph (one per input shape and trim), fed from HOST tensors as a DataLoader would
+    graphed = evaluation.GraphedPredict(models)
+    host = {k: torch.from_numpy(np.ascontiguousarray(batch[k])) for k in ("x_history", "x_target", "x_global", "empty_num")}
+    for rep in range(3):                                # capture, then two replays (the second with other data in between)
+        s_g, live_g = graphed(host)
+        assert torch.equal(live_g, live) and torch.allclose(s_g, scores, rtol=1e-5, atol=1e-7)
+        if rep == 1:
+            other = dict(host, x_history=host["x_history"].flip(0).contiguous())
+            s_o, _ = graphed(other)
+            assert not torch.allclose(s_o, scores, rtol=1e-5, atol=1e-7)
+    less = dict(host, empty_num=host["empty_num"] - 1)  # another trim: another graph, one more candidate column
+    s_l, live_l = graphed(less)
+    assert s_l.shape[1] == scores.shape[1] + 1 and len(graphed.graphs) == 2
     # validation numbers (verify.py:19-43) against the oracle's AUC on the same scores
     auc_v, tpr_v = evaluation.validate(models, [tb])
     want_auc = np.mean([orc.row_auc(batch["label"][b, :len(r)], r) for b, r in enumerate(ref)])
