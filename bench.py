@@ -63,9 +63,9 @@ def parse():
                     help="capture the step in a HIP graph and time graph replays (per-kernel event timing then "
                          "comes from 3 extra eager steps outside the timed region)")
     ap.add_argument("--eager", action="store_true",
-                    help="never replay a graph.  Default (neither flag): eager when a step takes >= 10 ms (C3, C5: the ~600 "
-                         "launches of a step hide behind the kernels and the heavy kernels can be event-timed inside the timed "
-                         "region), hipGraph replay when it is shorter (the step is then bound by host launches)")
+                    help="never replay a graph.  Default (neither flag): hipGraph replay when a step takes < 10 ms; above that "
+                         "whichever of the two steps faster in a two-step probe after the warm-up (C3: the captured step, which has "
+                         "no host-side gaps; C5: eager)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="(default since round 3) no HIP event pairs inside the timed region: the per-kernel durations and the "
@@ -458,6 +458,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    auto_probe = None
     if not args.graph and not args.eager and world == 1 and not use_dist:
         # launch mode by measurement: two eager steps (after two warm-up steps), mean wall time per step
         for _ in range(2):
@@ -467,8 +468,11 @@ def main():
         for _ in range(2):
             trainer.train_step(model, opt, tb, reducer)
         sync()
-        if (time.perf_counter() - t_probe) / 2 < 10e-3:
-            args.graph = True
+        t_eager = (time.perf_counter() - t_probe) / 2
+        if t_eager < 10e-3:
+            args.graph = True                          # launch-bound sizes: always the captured step
+        else:
+            auto_probe = t_eager                       # decided below, once the graph exists: whichever steps faster
     # Small shapes run their two attentions on two streams (modules.UserInvariantInterestModel.forward).  A kernel that
     # shares the chip with a kernel of the other branch cannot be priced against a roofline, so every event-timed step runs
     # on ONE stream; the timed region uses both only where no kernel events are taken inside it (graph replay).
@@ -497,7 +501,21 @@ def main():
             del os.environ["NRM_WGRAD_STREAM"]
         else:
             os.environ["NRM_WGRAD_STREAM"] = prev_wg
-        if args.graph:
+        if auto_probe is not None:
+            # big steps: the captured step saves the host-side gaps of an eager one (C3: 31.97 -> 31.59 ms) unless its fixed
+            # dependencies cost more than they save (C5: 117.4 -> 120.7 ms): two replays against the eager probe decide
+            step = trainer.GraphedTrainStep(model, opt, tb)
+            step.replay()
+            sync()
+            t_probe = time.perf_counter()
+            for _ in range(2):
+                step.replay()
+            sync()
+            args.graph = (time.perf_counter() - t_probe) / 2 < auto_probe
+            run = step.replay if args.graph else (lambda: trainer.train_step(model, opt, tb, reducer))      # noqa: E731
+            if not args.graph:
+                del step
+        elif args.graph:
             step = trainer.GraphedTrainStep(model, opt, tb)
             run = step.replay
         else:
