@@ -1396,9 +1396,13 @@ _unit_grads = {}
 
 
 def unit_grad(like):
+    """The cached scalar 1 of ``like``'s device -- or None while a stream capture is under way and none exists yet (a tensor
+    created inside a capture gets its value only when the graph is replayed; backward(None) then lets autograd seed itself)."""
     key = like.device.index if like.device.index is not None else torch.cuda.current_device()
     u = _unit_grads.get(key)
     if u is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
         u = _unit_grads[key] = torch.ones((), dtype=torch.float32, device=like.device)
     return u
 
