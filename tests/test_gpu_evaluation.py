@@ -188,3 +188,27 @@ def test_full_size_inference_properties(lib):
         n = int(live[b])
         assert len(ref[j]) == n
         assert rel_err(whole[b, :n].cpu().numpy(), ref[j]) < 1e-3
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_bench_inference_mode_prints_the_contract_line(lib, graph):
+    """`bench.py --mode infer [--graph]` (reference test.py:31-74: the OTHER caller of the hot path): one JSON line with the
+    throughput, the forward kernel's roofline (timed on one-stream batches) and -- eager or as a captured graph -- the same
+    fields."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "infer", "--workload", "ref-test80", "--steps", "5", "--warmup", "2",
+           "--no-cpu-baseline"] + (["--graph"] if graph else [])
+    pr = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+    assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in pr.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["unit"] == "impressions/s" and line["value"] > 0 and line["n_gpus"] == 1 and line["higher_is_better"] is True
+    assert line["config"]["mode"] == "infer" and line["config"]["batch"] == 80
+    assert ("hipGraph" in line["config"]["launch"]) == graph
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and r["mean_launch_ms"] > 0 and "no z store" in r["kernel"]
