@@ -263,15 +263,23 @@ __global__ __launch_bounds__(256) void small_linear_relu_bwd_kernel(const XT* __
             }
         }
     }
-    const int lane = threadIdx.x & 63;
+    // wave sums -> LDS -> one float atomic per output and WORKGROUP (all workgroups hit the same N * (K + 1) addresses: with one
+    // atomic per wave this tail was most of the kernel)
+    __shared__ float part[4][SL_NMAX * (SL_KMAX + 1)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int n = 0; n < SL_NMAX; ++n)
 #pragma unroll
         for (int k = 0; k <= SL_KMAX; ++k) {
             const float v = wave_sum64(acc[n][k]);
-            if (lane == 0 && n < N && (k < K || k == SL_KMAX) && v != 0.f)
-                atomicAdd(dwb + (k == SL_KMAX ? N * K + n : n * K + k), v);
+            if (lane == 0) part[wave][n * (SL_KMAX + 1) + k] = v;
         }
+    __syncthreads();
+    if (threadIdx.x < SL_NMAX * (SL_KMAX + 1)) {
+        const int n = threadIdx.x / (SL_KMAX + 1), k = threadIdx.x - n * (SL_KMAX + 1);
+        const float v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        if (n < N && (k < K || k == SL_KMAX) && v != 0.f) atomicAdd(dwb + (k == SL_KMAX ? N * K + n : n * K + k), v);
+    }
 }
 
 hipError_t small_linear_relu_fwd_launch(const void* x, int x_is_f64, const float* w, const float* b, float* y, long R, int K, int N,
@@ -288,8 +296,8 @@ hipError_t small_linear_relu_bwd_launch(const void* x, int x_is_f64, const float
                                         long R, int K, int N, float* dwb, hipStream_t st) {
     if (R <= 0) return hipSuccess;
     if (K < 1 || K > SL_KMAX || N < 1 || N > SL_NMAX || lddy < N) return hipErrorInvalidValue;
-    long blocks = (R + 255) / 256;
-    if (blocks > 512) blocks = 512;                                      // 40 atomics per wave at the end: keep the waves few and long
+    long blocks = (R + 255) / 256;                                       // one row per thread up to 256 workgroups (one atomic per output each)
+    if (blocks > 256) blocks = 256;
     if (x_is_f64) hipLaunchKernelGGL(small_linear_relu_bwd_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, st, (const double*)x, w, b, dy, lddy, R, K, N, dwb);
     else          hipLaunchKernelGGL(small_linear_relu_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, w, b, dy, lddy, R, K, N, dwb);
     return hipGetLastError();
