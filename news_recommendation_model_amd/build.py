@@ -10,6 +10,7 @@ import os
 import shutil
 import subprocess
 import sys
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -56,7 +57,10 @@ def build(force=False, verbose=True, extra_flags=(), lib=None):
     if not force and not extra_flags and not needs_build():
         return out
     hipcc = _hipcc()
-    objdir = OBJDIR if not extra_flags else OBJDIR + "_" + "".join(c if c.isalnum() else "_" for c in " ".join(extra_flags))
+    # objects of variant builds (scripts/_diag) live outside the package: what ships to the GPU box is the product only
+    objdir = OBJDIR if not extra_flags else os.path.join(
+        os.environ.get("NRM_DIAG_OBJDIR", os.path.join(tempfile.gettempdir(), "nrm_build_variants")),
+        "".join(c if c.isalnum() else "_" for c in " ".join(extra_flags)))
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [os.path.join(HERE, "..", "include", "nrm_hotpath.h")]
     hdr_time = max(os.path.getmtime(h) for h in headers)

@@ -53,12 +53,27 @@ class GraphedPredict:
     (80 impressions, test.py:46) are launch-bound when stepped eagerly -- ~0.9 ms of host work for ~0.35 ms of kernels.  Inputs
     are copied into static device buffers (from host or device tensors), the graph is replayed, and the returned ``scores`` /
     ``live`` are the graph's static outputs: valid until the next call with the same key (clone them to keep them).
-    At most ``max_graphs`` graphs are kept (least recently used first out)."""
+    At most ``max_graphs`` graphs are kept (least recently used first out).
+
+    Weights may change between calls (validation after every epoch, another checkpoint loaded into the same model).  A graph
+    bakes in ADDRESSES: parameters and buffers are read where they live, and the dense / side-projection GEMMs read the packed
+    weight images of ``ops._pack``, which were filled during the warm-up calls BEFORE the capture (no pack launch is recorded).
+    So every call compares (a) the addresses of all parameters and buffers and the generation of the packed-weight cache --
+    a change (``.to()``, ``FlatAdam`` re-seating the parameters, ``ops.invalidate_packed_weights()``) drops every graph -- and
+    (b) their autograd version counters: a change (``load_state_dict``, ``torch.optim`` steps, any in-place op) re-packs the
+    images IN PLACE with one eager launch (``ops.repack_persistent``) before the replay.  ``trainer.FlatAdam.step()`` updates
+    weights through a raw pointer but refreshes the same images itself."""
 
     def __init__(self, models, max_graphs=16):
         self.models = list(models)
         self.max_graphs = max_graphs
         self.graphs = {}
+        self._addresses = None
+        self._versions = None
+
+    def _weights_state(self):
+        tensors = [t for m in self.models for t in list(m.parameters()) + list(m.buffers())]
+        return (tuple(t.data_ptr() for t in tensors) + (ops.packed_weights_generation(),)), tuple(t._version for t in tensors)
 
     @torch.no_grad()
     def __call__(self, batch):
@@ -66,6 +81,13 @@ class GraphedPredict:
         if native.kernel_events is not None:
             raise RuntimeError("per-kernel event timing cannot be recorded inside a graph capture")
         dev = next(self.models[0].parameters()).device
+        addresses, versions = self._weights_state()
+        if addresses != self._addresses:
+            self.graphs.clear()                                       # captured addresses are gone: capture again
+            self._addresses = addresses
+        elif versions != self._versions and self.graphs:
+            ops.repack_persistent([p for m in self.models for p in m.parameters()])      # same buffers the graphs read
+        self._versions = versions
         e_in = batch["empty_num"]
         trim = int(e_in.min()) if e_in.numel() else 0                 # host decision, as in predict()
         names = ("x_history", "x_target", "x_global", "empty_num")
@@ -89,6 +111,7 @@ class GraphedPredict:
             ent = (graph, static, scores, live)
             while len(self.graphs) >= self.max_graphs:
                 self.graphs.pop(next(iter(self.graphs)))
+            self._addresses, self._versions = self._weights_state()   # (the warm-up may have created the packed images)
         else:
             for k in names:
                 ent[1][k].copy_(batch[k], non_blocking=True)

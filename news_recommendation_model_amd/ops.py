@@ -117,6 +117,7 @@ class _PackedWeights:
     def __init__(self):
         self.entries = {}
         self.epoch = 0
+        self.generation = 0          # bumped when images are FREED (invalidate_packed_weights): captured graphs that read them are stale
 
 
 class _PackEntry:
@@ -207,6 +208,13 @@ def invalidate_packed_weights():
     ``.to()`` and ``torch.optim`` steps are noticed on their own, ``trainer.FlatAdam`` refreshes the images itself."""
     _packs.entries.clear()
     _packs.epoch += 1
+    _packs.generation += 1
+
+
+def packed_weights_generation():
+    """Changes whenever cached weight images were released (their memory may be reused): what evaluation.GraphedPredict
+    compares before replaying a graph that reads them."""
+    return _packs.generation
 
 
 import os as _os
@@ -1417,7 +1425,10 @@ def _loss_backward(ctx, gl, _a, _b):
     except RuntimeError:                                  # fake / functional tensors (tracing) have no address: the general formula
         unit = False
     if unit:
-        return dout, ddelta, None, None, None
+        # dout: the saved buffer itself (a strided view: AccumulateGrad never adopts it).  ddelta: a COPY -- AccumulateGrad adopts a
+        # contiguous gradient as delta.grad and a later in-place accumulation would rewrite what a second backward through a
+        # retained graph reads (user_num + 1 floats: one tiny launch)
+        return dout, ddelta.clone(), None, None, None
     return dout * gl, ddelta * gl, None, None, None
 
 

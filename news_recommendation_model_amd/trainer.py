@@ -208,7 +208,14 @@ class IndexErrorWatch:
     ``before_step()`` just reads it: the error surfaces at the start of the step after the offending batch when the device keeps
     up with the host, and ``max_lag`` + 1 steps after it at the latest (``after_step()`` records an event per step and
     ``before_step()`` waits for the one that is ``max_lag`` steps old) -- not at the epoch's end, and at no cost per step beyond
-    one event record."""
+    one event record.
+
+    What this is NOT: the reference raises BEFORE any update; here the offending batch's step (computed with the clamped ids) and
+    up to ``max_lag`` following steps have already been applied to the weights, both Adam moments and ``delta`` when the
+    exception arrives -- the exception says so.  A caller that must not train on a bad batch uses the strict mode instead
+    (``train_step(..., strict_ids=True)`` / ``validate_batch_ids``: ids checked on the device before the step is enqueued, one
+    host synchronisation per step).  When the flag is found raised, every step still in flight is waited for BEFORE the flag is
+    cleared, so a step enqueued earlier cannot raise it again for an unrelated later batch."""
 
     def __init__(self, device, max_lag=2):
         from . import ops
@@ -226,10 +233,44 @@ class IndexErrorWatch:
         while self.pending and (len(self.pending) > self.max_lag or self.pending[0].query()):
             self.pending.pop(0).synchronize()
         if int(self.flag[0]):
-            self.pending.clear()
+            in_flight = len(self.pending)
+            while self.pending:                             # drain: steps still in flight may set the flag again
+                self.pending.pop(0).synchronize()
             self.flag.zero_()
             raise IndexError("index out of range (a category / type / time table index of a packed feature row, or a user "
-                             "id outside delta) in a batch of one of the last steps")
+                             f"id outside delta) in a batch of one of the last {in_flight + 1} steps; those steps ran with the "
+                             "offending ids clamped and HAVE ALREADY UPDATED the weights, the Adam moments and delta (the "
+                             "reference raises before any update: use train_step(..., strict_ids=True) for that behaviour)")
+
+
+def validate_batch_ids(model, batch):
+    """The reference's IndexError BEFORE anything is enqueued (strict mode of train_step): every table index of the packed rows
+    (time4 | text_img[P] | category | sub-categories | sentiment | type ...: models/user_invariant_interest_model.py:14-22,58-71)
+    and every user id (models/user_model.py:40; negative ids count from the end, as torch indexing does) is range-checked on the
+    device; ONE host synchronisation.  The asynchronous default is IndexErrorWatch."""
+    inv = model.invariant_interest_model
+    d = inv._dims
+    P, ns = d.pca_vector, d.n_subcat
+    bad = torch.zeros((), dtype=torch.bool, device=batch["x_history"].device)
+    tables = (inv.year_embedding[0].num_embeddings, inv.month_embedding[0].num_embeddings, inv.day_embedding[0].num_embeddings,
+              inv.hour_embedding[0].num_embeddings)
+    n_cat, n_type = inv.category_embedding[0].num_embeddings, inv.type_embedding[0].num_embeddings
+    for x in (batch["x_history"], batch["x_target"]):
+        if x.numel() == 0:
+            continue
+        for c, n in enumerate(tables):
+            col = x[..., c].long()
+            bad |= ((col < 0) | (col >= n)).any()                        # (F.embedding refuses negative indices too)
+        ids = x[..., 4 + P:4 + P + 1 + ns].long()                     # category and its sub-category slots share one table
+        bad |= ((ids < 0) | (ids >= n_cat)).any()
+        typ = x[..., 4 + P + 1 + ns + d.n_sentiment].long()
+        bad |= ((typ < 0) | (typ >= n_type)).any()
+    n = model.delta.numel()
+    uid = batch["user_id"].long()
+    bad |= ((uid < -n) | (uid >= n)).any()
+    if bool(bad):                                                      # the one synchronisation
+        raise IndexError("index out of range in self (a category / type / time table index of a packed feature row, or a user id "
+                         "outside delta); nothing was enqueued, no weight was updated")
 
 
 _watches = {}
@@ -244,12 +285,17 @@ def _index_watch(device):
     return w
 
 
-def train_step(model, optimizer, batch, reducer: FlatGradReducer | None = None, alpha=0.95, defer_reductions=True):
+def train_step(model, optimizer, batch, reducer: FlatGradReducer | None = None, alpha=0.95, defer_reductions=True,
+               strict_ids=False):
     """One step of train.py:69-75 on device-resident tensors; returns (loss, out) detached.  An out-of-range id of an EARLIER
-    step raises IndexError here, before this step's work is enqueued (IndexErrorWatch)."""
+    step raises IndexError here, before this step's work is enqueued (IndexErrorWatch: asynchronous, the offending step has
+    been applied by then).  ``strict_ids=True``: the ids of THIS batch are checked first (validate_batch_ids, one host
+    synchronisation) and the IndexError is raised before anything is enqueued -- the reference's behaviour."""
     watch = _index_watch(batch["x_history"].device) if not torch.cuda.is_current_stream_capturing() else None
     if watch is not None:
         watch.before_step()
+    if strict_ids:
+        validate_batch_ids(model, batch)
     out = model(batch["x_history"], batch["x_target"], batch["x_global"])
     loss = model.loss(batch["user_id"], out, batch["label"], alpha)
     if isinstance(optimizer, FlatAdam):

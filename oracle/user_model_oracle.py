@@ -21,6 +21,28 @@ import torch
 import torch.nn.functional as F
 
 
+# Arithmetic of the restatement.  float32 is the reference's (models/user_invariant_interest_model.py:74-75 cast the float64
+# DataLoader rows to float32) and the only mode that is pinned / timed.  ``precision(torch.float64)`` re-runs the same
+# formulas in float64 for ERROR ANALYSIS in tests/ (what an fp32 sum with heavy cancellation can be held to); parameters must
+# then be float64 as well (``to_torch_params(sd, dtype=torch.float64)``).
+COMPUTE_DTYPE = torch.float32
+
+
+class precision:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global COMPUTE_DTYPE
+        self.prev, COMPUTE_DTYPE = COMPUTE_DTYPE, self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        global COMPUTE_DTYPE
+        COMPUTE_DTYPE = self.prev
+        return False
+
+
 # --------------------------------------------------------------------------- building blocks
 def mlp(p, prefix, x):
     """Linear(d -> d//4) -> exact-erf GELU -> Linear(d//4 -> out).  models/attention_model.py:29-32
@@ -84,8 +106,8 @@ def invariant_interest(p, x_history, x_target, n_sub=5, n_sent=3, return_aux=Fal
         # raises RuntimeError for an empty batch, an empty history and an empty candidate list (train and eval;
         # tests/golden/MANIFEST.json "degenerate").  The attention module alone accepts them (empty scores).
         raise RuntimeError("cannot reshape tensor of 0 elements (empty batch / history / candidate list)")
-    time_h, ti_h, cat_h, sub_h, sen_h, typ_h, read_h, scroll_h = _split_cols(x_history.float(), widths)
-    time_t, ti_t, cat_t, sub_t, sen_t, typ_t = _split_cols(x_target.float(), widths[:6])
+    time_h, ti_h, cat_h, sub_h, sen_h, typ_h, read_h, scroll_h = _split_cols(x_history.to(COMPUTE_DTYPE), widths)
+    time_t, ti_t, cat_t, sub_t, sen_t, typ_t = _split_cols(x_target.to(COMPUTE_DTYPE), widths[:6])
 
     lab_h = torch.cat([_label_features(p, cat_h, sub_h, sen_h, typ_h), _time_features(p, time_h),
                        read_h, scroll_h], dim=2)                                   # :77
@@ -105,7 +127,7 @@ def invariant_interest(p, x_history, x_target, n_sub=5, n_sent=3, return_aux=Fal
 
 def instant_interest(p, x_global):
     """ReLU(Linear(3->8)).  models/user_instant_interest_model.py:20-23."""
-    return torch.relu(F.linear(x_global.float(), p["instant_interest_model.out_fc.0.weight"],
+    return torch.relu(F.linear(x_global.to(COMPUTE_DTYPE), p["instant_interest_model.out_fc.0.weight"],
                                p["instant_interest_model.out_fc.0.bias"]))
 
 
@@ -135,7 +157,7 @@ def user_model_forward(p, x_history, x_target, x_global, training=True, bn_state
     x = mlp(p, "gate", c) * e2                                     # :33  (gate multiplies the RAW concat)
     r = mlp(p, "out_mlp", mlp(p, "mlp", x)).reshape(B, T)          # :33-34
     if return_aux:
-        aux.update({"eu_H": eu_H, "ec": ec, "eu_L": eu_L})
+        aux.update({"eu_H": eu_H, "ec": ec, "eu_L": eu_L, "e2": e2, "c": c, "bn_var": var_b})
         return r, aux
     return r
 
@@ -149,7 +171,7 @@ def bce_mean(prob, y):
 
 def user_model_loss(p, user_id, out, label, alpha=0.95):
     """(1-alpha)*BCE(softmax_T(out)) + alpha*BCE(softmax_T(out + delta[id])).  models/user_model.py:37-43."""
-    y = label.float()
+    y = label.to(COMPUTE_DTYPE)
     l1 = bce_mean(torch.softmax(out, dim=1), y)
     d = p["delta"][user_id.long()][:, None].expand(-1, y.shape[1])
     l2 = bce_mean(torch.softmax(out + d, dim=1), y)
@@ -160,10 +182,12 @@ def user_model_loss(p, user_id, out, label, alpha=0.95):
 BUFFER_KEYS = ("bn.running_mean", "bn.running_var", "bn.num_batches_tracked")
 
 
-def to_torch_params(sd_np, requires_grad=True):
+def to_torch_params(sd_np, requires_grad=True, dtype=None):
     p = {}
     for k, v in sd_np.items():
         t = torch.from_numpy(np.array(v, copy=True))
+        if dtype is not None and t.is_floating_point():
+            t = t.to(dtype)
         if k not in BUFFER_KEYS and requires_grad:
             t.requires_grad_(True)
         p[k] = t

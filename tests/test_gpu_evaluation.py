@@ -76,6 +76,70 @@ def test_predict_follows_test_py_semantics(lib):
     assert abs(auc_v - want_auc) < 1e-5 and abs(tpr_v - want_tpr) < 1e-9
 
 
+def test_graphed_predict_follows_weight_changes(lib, tmp_path):
+    """a captured predict() reads the packed weight images that ops._pack filled BEFORE the capture.  Weights that
+    change afterwards -- load_state_dict of another checkpoint, a torch.optim step, FlatAdam (which re-seats the parameters), a
+    dropped pack cache -- must show up in the next replay: graphed == eager after every one of them, and != the scores before."""
+    from news_recommendation_model_amd import evaluation, ops, synth, trainer
+    case, dims, batch, sd, fx = load_case("tiny_train")
+    batch["empty_num"] = np.zeros(case["B"], dtype=np.int64)
+    user_num = int(batch["user_num"])
+    model = trainer.build_model(dims, user_num, sd, device="cuda").eval()
+    tb = trainer.batch_to_device(batch, "cuda")
+    tb["empty_num"] = torch.from_numpy(batch["empty_num"])
+    graphed = evaluation.GraphedPredict([model])
+
+    def both():
+        g, _ = graphed(tb)
+        g = g.clone()
+        e, _ = evaluation.predict([model], tb)
+        assert torch.allclose(g, e, rtol=1e-5, atol=1e-7), float((g - e).abs().max())
+        return g
+
+    s0 = both()
+    assert torch.equal(both(), s0) and len(graphed.graphs) == 1
+    # (1) other weights through load_state_dict (in place: same addresses, version counters move) -> re-pack, same graph
+    sd2 = synth.make_state_dict(dims, seed=9, user_num=user_num)
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd2.items()}, strict=False)
+    graph_before = next(iter(graphed.graphs.values()))[0]
+    s1 = both()
+    assert not torch.allclose(s1, s0, rtol=1e-3, atol=1e-6)
+    assert next(iter(graphed.graphs.values()))[0] is graph_before          # replayed, not re-captured
+    # (2) a torch.optim step
+    model.train()
+    opt = trainer.make_optimizer(model, lr=5e-2)
+    out = model(tb["x_history"], tb["x_target"], tb["x_global"])
+    model.loss(tb["user_id"], out, tb["label"]).backward()
+    opt.step()
+    opt.zero_grad()
+    model.eval()
+    s2 = both()
+    assert not torch.allclose(s2, s1, rtol=1e-3, atol=1e-6)
+    # (3) the checkpoint loader of evaluation.py (test.py:160)
+    path = str(tmp_path / "other.pth")
+    ref_model = trainer.build_model(dims, user_num, sd, device="cuda")
+    evaluation.save_checkpoint(ref_model, path)
+    evaluation.load_checkpoint(model, path)
+    s3 = both()
+    assert torch.allclose(s3, s0, rtol=1e-5, atol=1e-7)                     # back on the first weights (delta is not read by forward)
+    # (4) the pack cache dropped (its buffers may be reused by the allocator): the graph must be re-captured, not replayed
+    ops.invalidate_packed_weights()
+    junk = [torch.randn(1 << 16, device="cuda") for _ in range(8)]          # noqa: F841  (take the freed blocks)
+    s4 = both()
+    assert torch.allclose(s4, s0, rtol=1e-5, atol=1e-7)
+    # (5) FlatAdam re-seats every parameter into its flat buffer (new addresses) and updates through a raw pointer
+    model.train()
+    fopt = trainer.FlatAdam(model, lr=5e-2)
+    trainer.train_step(model, fopt, tb)
+    model.eval()
+    s5 = both()
+    assert not torch.allclose(s5, s0, rtol=1e-3, atol=1e-6)
+    trainer.train_step(model.train(), fopt, tb)                             # same addresses now: FlatAdam refreshes the images itself
+    model.eval()
+    s6 = both()
+    assert not torch.allclose(s6, s5, rtol=1e-3, atol=1e-6)
+
+
 def test_checkpoint_roundtrip_drops_delta(lib, tmp_path):
     from news_recommendation_model_amd import evaluation, trainer
     case, dims, batch, sd, fx = load_case("tiny_train")
@@ -145,6 +209,26 @@ def test_train_epochs_raises_indexerror_for_an_out_of_range_id(lib):
     with pytest.raises(IndexError):
         trainer.train_epochs(model, opt, lambda: iter(hosts), 1, on_batch=lambda e, i, l, a: seen.append(i))
     assert seen and seen[-1] <= 1 + 3
+    ops.check_index_errors("cuda")
+    # strict mode: the reference raises BEFORE any update -- ids validated on the device before the step is enqueued
+    steps_before, w_before = opt.steps, opt.flat_param.clone()
+    bad = trainer.batch_to_device(hosts[1], "cuda")
+    with pytest.raises(IndexError, match="nothing was enqueued"):
+        trainer.train_step(model, opt, bad, strict_ids=True)
+    torch.cuda.synchronize()
+    assert opt.steps == steps_before and torch.equal(opt.flat_param, w_before)
+    bad_uid = trainer.batch_to_device(hosts[0], "cuda")
+    bad_uid["user_id"] = bad_uid["user_id"].clone()
+    bad_uid["user_id"][2] = user_num + 1                                        # delta has user_num + 1 entries
+    with pytest.raises(IndexError, match="nothing was enqueued"):
+        trainer.train_step(model, opt, bad_uid, strict_ids=True)
+    trainer.train_step(model, opt, trainer.batch_to_device(hosts[0], "cuda"), strict_ids=True)     # a clean batch passes
+    ops.check_index_errors("cuda")
+    # the asynchronous watch says what it could not prevent
+    trainer.train_step(model, opt, bad)
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError, match="ALREADY UPDATED"):
+        trainer.train_step(model, opt, trainer.batch_to_device(hosts[0], "cuda"))
     ops.check_index_errors("cuda")
     hosts[1]["x_history"][3, 2, cat_col] = 1
     assert len(trainer.train_epochs(model, opt, lambda: iter(hosts), 1)) == 1

@@ -5,8 +5,8 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import (MODEL_CASES, TRAJ_CASES, ZERO_GRAD_KEYS, assert_first_adam_update, check_trajectory, load_case,
-                         load_trajectory, pick, rel_err)
+from golden_util import (II_B, II_W, MODEL_CASES, TRAIN_CASES, TRAJ_CASES, ZERO_GRAD_KEYS, assert_first_adam_update, check_trajectory,
+                         grad_tolerance, instant_interest_grad_bounds, load_case, load_trajectory, pick, rel_err)
 from oracle import user_model_oracle as orc
 
 
@@ -44,6 +44,32 @@ def test_oracle_matches_fixture(name):
     for k in ("bn.running_mean", "bn.running_var"):
         assert rel_err(pick(p[k].numpy(), full), fx["after/" + k]) < 1e-5, k
     np.testing.assert_allclose(orc.batch_auc(batch["label"], fx["r"]), fx["auc"], atol=1e-12)
+
+
+@pytest.mark.parametrize("name", [c for c in TRAIN_CASES if c not in ("c5_long",)])
+def test_instant_interest_gradient_bound_is_tight_and_sufficient(name):
+    """The derived tolerance of the two instant-interest gradients (golden_util.instant_interest_grad_bounds; used by the GPU
+    parity tests instead of round 3's flat floor): against the FLOAT64 gradient of the oracle, (1) the reference's own fp32
+    gradient (fixture) and the fp32 oracle's are inside it with the NOISE term alone (no relative allowance at all), and
+    (2) it is far below the gradient itself -- a zeroed weight or bias gradient is outside it by a wide margin."""
+    case, dims, batch, sd, fx = load_case(name)
+    bounds = instant_interest_grad_bounds(sd, batch)
+    p64 = orc.to_torch_params(sd, dtype=torch.float64)
+    tb = {k: torch.from_numpy(v) for k, v in batch.items() if isinstance(v, np.ndarray) and v.ndim > 0}
+    with orc.precision(torch.float64):
+        r = orc.user_model_forward(p64, tb["x_history"], tb["x_target"], tb["x_global"], training=True)
+        orc.user_model_loss(p64, tb["user_id"], r, tb["label"]).backward()
+    p32 = orc.to_torch_params(sd)
+    _, _, g32 = orc.train_step(p32, {"step": 0, "m": {}, "v": {}}, tb, lr=0.0)
+    for k in (II_W, II_B):
+        g64 = p64[k].grad.numpy().reshape(-1)
+        noise_only = grad_tolerance(k, np.zeros(1), 0.0, bounds)          # II_NOISE * S, per entry
+        for other in (np.asarray(fx["grad/" + k]).reshape(-1), g32[k].numpy().reshape(-1)):
+            assert (np.abs(other - g64) <= noise_only.reshape(-1)).all(), k
+        tol = grad_tolerance(k, g64, 1e-2, bounds).reshape(-1)
+        live = bounds[k].reshape(-1) > 0                                  # (dead ReLU units: gradient exactly 0)
+        assert np.abs(g64)[live].max() > 20 * tol[live].max(), (k, float(np.abs(g64).max()), float(tol.max()))
+        assert not (np.abs(0.0 - g64) <= tol).all(), k                    # the mutation the GPU test applies to the kernel
 
 
 @pytest.mark.parametrize("name", TRAJ_CASES)
