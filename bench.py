@@ -63,9 +63,13 @@ def parse():
                     help="capture the step in a HIP graph and time graph replays (per-kernel event timing then "
                          "comes from 3 extra eager steps outside the timed region)")
     ap.add_argument("--eager", action="store_true",
-                    help="never replay a graph.  Default (neither flag): hipGraph replay when a step takes < 10 ms; above that "
-                         "whichever of the two steps faster in a two-step probe after the warm-up (C3: the captured step, which has "
-                         "no host-side gaps; C5: eager)")
+                    help="never replay a graph.  Default (neither flag): both launch modes are timed over --probe-steps steps and "
+                         "reported (launch_probe); hipGraph replay when the eager step takes < 10 ms or the replay is >= 1 %% faster "
+                         "(C3: the captured step, which has no host-side gaps; C5: eager).  Same for --gpus N > 1 with RCCL: the "
+                         "captured step then contains the in-stream all-reduce")
+    ap.add_argument("--batches", type=int, default=4,
+                    help="resident synthetic batches per rank the steps cycle through (all in HBM before the timed region starts)")
+    ap.add_argument("--probe-steps", type=int, default=10, help="steps per launch mode in the eager-vs-hipGraph probe (>= 10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="(default since round 3) no HIP event pairs inside the timed region: the per-kernel durations and the "
@@ -148,6 +152,7 @@ def cpu_baseline(dims, wl, seconds, cpu_batch, mma="f32"):
     if check is None:
         gk = g_cpu["invariant_interest_model.label_attention.mlp.fc1.weight"]
         check = {"logit_max_rel_err": float((r_dev - r_cpu).abs().max() / r_cpu.abs().max()),
+                 "oracle_loss": round(float(l_cpu), 6), "hip_loss": round(l_dev, 6),
                  "loss_rel_err": abs(l_dev - float(l_cpu)) / abs(float(l_cpu)),
                  "attention_fc1_grad_max_rel_err": float((g_dev - gk).abs().max() / gk.abs().max())}
     n, t0 = 0, time.perf_counter()
@@ -187,16 +192,20 @@ def fwd_auc_parity(dev, mma="f32", case_name="c3_large"):
         sys.path.pop(0)
 
 
-def collective_stats(opt, world):
+def collective_stats(opt, world, fallback_events=None):
     """Mean duration of the step's one all-reduce over the timed steps (event pair on the launch stream around it: the wait of
     the compute stream for the collective is inside) and its bus bandwidth 2 (N-1)/N * bytes / t -- what a scaling run needs to
-    tell whether xGMI is the limiter."""
+    tell whether xGMI is the limiter.  When the timed region replays a captured step (no events inside a graph) the figure
+    comes from the three eager one-stream steps before it (``fallback_events``)."""
     ev = getattr(opt, "collective_events", None)
+    src = "timed region"
+    if not ev and fallback_events:
+        ev, src = fallback_events, "3 eager one-stream steps before the timed region"
     if not ev:
         return {"allreduce_ms": None, "bus_GBps": None}
     ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     bus = (2.0 * (world - 1) / world * opt.nbytes / (ms * 1e-3) / 1e9) if world > 1 and ms > 0 else 0.0
-    return {"allreduce_ms": round(ms, 4), "bus_GBps": round(bus, 2), "allreduce_events": len(ev)}
+    return {"allreduce_ms": round(ms, 4), "bus_GBps": round(bus, 2), "allreduce_events": len(ev), "allreduce_timed_in": src}
 
 
 HEAVY = ("nrm_pwattn_fwd", "pwattn_bwd_e_bt", "pwattn_bwd_e_dw", "pwattn_bwd_e_bh", "pwattn_bwd_rw_dtdh", "nrm_pwattn_bwd_dz")   # event-timed inside the timed region
@@ -444,13 +453,18 @@ def main():
         # BASELINE config 2 names bf16: the dense layers run on the bf16 matrix cores as well (same hi/lo split as the attention)
         from news_recommendation_model_amd import ops as _o
         _o.set_dense_arithmetic(args.dtype)
-    # same weights on every rank (seed 1), a different batch per rank (seed = rank)
+    # same weights on every rank (seed 1); every rank holds NB different batches resident in HBM and cycles through them, so the
+    # timed steps do not re-fit ONE batch (round 3: ~45 steps on one repeated batch drove the logits to 1e5 and the loss back up
+    # to 6.5 -- the reference's arithmetic does the same, but the printed loss said nothing)
+    from news_recommendation_model_amd import ops as _ops
     sd = synth.make_state_dict(dims, seed=1, user_num=user_num, perturb=False)
     model = trainer.build_model(dims, user_num, sd, device=dev, attention_mma=args.dtype).train()
     opt = trainer.FlatAdam(model)              # Adam(lr 1e-3, wd 1e-5) + zero_grad as one launch; flat grad buffer
     reducer = None                             # the all-reduce runs on opt.flat_grad (no gather copy)
-    batch = synth.make_batch(dims, B, H, T, seed=rank, user_num=user_num, dtype=np.float32)
-    tb = trainer.batch_to_device(batch, dev)
+    NB = max(1, args.batches)
+    tbs = [trainer.batch_to_device(synth.make_batch(dims, B, H, T, seed=rank * NB + i, user_num=user_num, dtype=np.float32), dev)
+           for i in range(NB)]
+    counter = {"i": 0}
 
     def sync():
         torch.cuda.synchronize()
@@ -458,25 +472,49 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    auto_probe = None
-    if not args.graph and not args.eager and world == 1 and not use_dist:
-        # launch mode by measurement: two eager steps (after two warm-up steps), mean wall time per step
-        for _ in range(2):
-            trainer.train_step(model, opt, tb, reducer)
+    def eager_step():
+        tb_ = tbs[counter["i"] % NB]
+        counter["i"] += 1
+        return trainer.train_step(model, opt, tb_, reducer)
+
+    graphs = []
+
+    def capture_graphs():
+        """One captured step per resident batch (static input buffers = the batches themselves), sharing one memory pool."""
+        pool = None
+        for j in range(NB):
+            g = trainer.GraphedTrainStep(model, opt, tbs[j], warmup=3 if j == 0 else 1, pool=pool)
+            pool = g.graph.pool()
+            graphs.append(g)
+
+    def graph_step():
+        g = graphs[counter["i"] % NB]
+        counter["i"] += 1
+        return g.replay()
+
+    def time_steps(fn, n):
         sync()
-        t_probe = time.perf_counter()
-        for _ in range(2):
-            trainer.train_step(model, opt, tb, reducer)
+        t_ = time.perf_counter()
+        for _ in range(n):
+            fn()
         sync()
-        t_eager = (time.perf_counter() - t_probe) / 2
-        if t_eager < 10e-3:
-            args.graph = True                          # launch-bound sizes: always the captured step
-        else:
-            auto_probe = t_eager                       # decided below, once the graph exists: whichever steps faster
+        t_ = (time.perf_counter() - t_) / n
+        if use_dist:                                   # every rank must take the same decision: the slowest rank's time
+            tt_ = torch.tensor([t_], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            t_ = float(tt_.item())
+        return t_
+
+    # the very first step of the process (initial weights, batch 0): the loss the oracle reproduces (cpu_baseline leg)
+    l0, _ = eager_step()
+    first_step_loss = float(l0)
+
     # Small shapes run their two attentions on two streams (modules.UserInvariantInterestModel.forward).  A kernel that
     # shares the chip with a kernel of the other branch cannot be priced against a roofline, so every event-timed step runs
-    # on ONE stream; the timed region uses both only where no kernel events are taken inside it (graph replay).
+    # on ONE stream; the timed region uses both only where no kernel events are taken inside it.
     inv = model.invariant_interest_model
+    probe = {"steps": 0, "t_eager_ms": None, "t_graph_ms": None, "rule": None}
+    flop_meter = None
     if not args.timed_kernel_events:
         args.no_kernel_timing = True
     else:
@@ -484,48 +522,66 @@ def main():
     if args.graph or args.no_kernel_timing:
         # per-kernel durations cannot be event-timed inside a graph, and a kernel that shares the chip with a kernel of another
         # stream cannot be priced against a roofline: take them from 3 eager ONE-STREAM steps first (no second attention stream,
-        # no weight-gradient stream)
+        # no weight-gradient stream); the first of them also runs under the matrix-FLOP meter (roofline.step)
         inv.two_streams = False
         prev_wg = os.environ.get("NRM_WGRAD_STREAM")
         os.environ["NRM_WGRAD_STREAM"] = "0"
         for _ in range(2):
-            trainer.train_step(model, opt, tb, reducer)
+            eager_step()
         sync()
         native.kernel_events = []
-        for _ in range(3):
-            loss, _ = trainer.train_step(model, opt, tb, reducer)
+        if use_dist:
+            opt.collective_events = []                 # an event pair around the step's one all-reduce (eager steps only)
+        for k_ in range(3):
+            if k_ == 0:
+                _ops.flop_meter_start()
+            loss, _ = eager_step()
+            if k_ == 0:
+                flop_meter = _ops.flop_meter_stop()
         sync()
         events, native.kernel_events = native.kernel_events, None
+        table_collective_events, opt.collective_events = opt.collective_events, None
         inv.two_streams = None
         if prev_wg is None:
             del os.environ["NRM_WGRAD_STREAM"]
         else:
             os.environ["NRM_WGRAD_STREAM"] = prev_wg
-        if auto_probe is not None:
-            # big steps: the captured step saves the host-side gaps of an eager one (C3: 31.97 -> 31.59 ms) unless its fixed
-            # dependencies cost more than they save (C5: 117.4 -> 120.7 ms): two replays against the eager probe decide
-            step = trainer.GraphedTrainStep(model, opt, tb)
-            step.replay()
-            sync()
-            t_probe = time.perf_counter()
-            for _ in range(2):
-                step.replay()
-            sync()
-            t_graph = (time.perf_counter() - t_probe) / 2
-            t_probe = time.perf_counter()               # the eager probe again, in the same state of the box as the replays
-            for _ in range(2):
-                trainer.train_step(model, opt, tb, reducer)
-            sync()
-            auto_probe = min(auto_probe, (time.perf_counter() - t_probe) / 2)
-            args.graph = t_graph < 0.997 * auto_probe
-            run = step.replay if args.graph else (lambda: trainer.train_step(model, opt, tb, reducer))      # noqa: E731
+        # Launch mode of the timed region.  --graph / --eager force it.  Otherwise BOTH are timed over PROBE >= 10 steps in the
+        # same state of the box (two 2-step probes with a 0.3 % threshold were inside run-to-run noise), both times are
+        # reported, and the captured step is taken when a step is launch-bound (< 10 ms) or when it is at least 1 % faster.  With
+        # a process group (N > 1, or the one-rank RCCL rehearsal) the captured step CONTAINS the in-stream all-reduce; gloo (the
+        # one-GPU two-rank rehearsal) synchronises with the host inside its collective and cannot be captured.
+        can_capture = not use_dist or backend == "nccl"
+        capture_error = None
+        if args.graph and not can_capture:
+            raise SystemExit("bench.py --graph: a gloo all-reduce cannot be captured into a HIP graph (use the nccl backend)")
+        if not args.eager and can_capture:
+            PROBE = max(10, args.probe_steps)
+            t_eager = time_steps(eager_step, PROBE)
+            try:
+                capture_graphs()
+                ok = 1.0
+            except Exception as e:                      # noqa: BLE001 -- never let a failed capture cost the run its number
+                capture_error, ok = repr(e), 0.0
+                graphs.clear()
+            if use_dist:                                # a capture that failed on ANY rank: everybody steps eagerly
+                tt_ = torch.tensor([ok], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt_, op=dist.ReduceOp.MIN)
+                ok = float(tt_.item())
+            if ok:
+                t_graph = time_steps(graph_step, PROBE)
+                probe = {"steps": PROBE, "t_eager_ms": round(t_eager * 1e3, 4), "t_graph_ms": round(t_graph * 1e3, 4),
+                         "rule": "hipGraph replay if forced, if the eager step takes < 10 ms, or if the replay is >= 1 % faster"}
+                if not args.graph:
+                    args.graph = t_eager < 10e-3 or t_graph < 0.99 * t_eager
+            else:
+                graphs.clear()
+                if args.graph:
+                    raise SystemExit(f"bench.py --graph: capturing the step failed: {capture_error}")
+                probe = {"steps": PROBE, "t_eager_ms": round(t_eager * 1e3, 4), "t_graph_ms": None, "rule": f"capture failed: {capture_error}"}
             if not args.graph:
-                del step
-        elif args.graph:
-            step = trainer.GraphedTrainStep(model, opt, tb)
-            run = step.replay
-        else:
-            run = lambda: trainer.train_step(model, opt, tb, reducer)      # noqa: E731
+                graphs.clear()
+        run = graph_step if args.graph else eager_step
         for _ in range(args.warmup):
             run()
         sync()
@@ -536,16 +592,20 @@ def main():
             loss, _ = run()
         sync()
     else:
-        # the full per-kernel table comes from 3 extra eager steps outside the timed region; inside it only the four big
-        # attention kernels (the roofline candidates, 8 launches per step) are bracketed by events -- bracketing all
-        # ~600 launches of a step costs 1.5 % at C3 and 3-4x on the small shapes
+        # --timed-kernel-events (round-1/2 behaviour): the full per-kernel table comes from 3 extra eager steps outside the timed
+        # region; inside it only the four big attention kernels (8 launches per step) are bracketed by events
         inv.two_streams = False
+        table_collective_events = None
         for _ in range(args.warmup):
-            trainer.train_step(model, opt, tb, reducer)
+            eager_step()
         sync()
         native.kernel_events = []
-        for _ in range(3):                         # table steps: untimed, after the W warm-up steps
-            trainer.train_step(model, opt, tb, reducer)
+        for k_ in range(3):                        # table steps: untimed, after the W warm-up steps
+            if k_ == 0:
+                _ops.flop_meter_start()
+            eager_step()
+            if k_ == 0:
+                flop_meter = _ops.flop_meter_stop()
         sync()
         table_events = native.kernel_events
         native.kernel_event_tags = set(HEAVY)
@@ -554,16 +614,21 @@ def main():
             opt.collective_events = []
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            loss, _ = trainer.train_step(model, opt, tb, reducer)
+            loss, _ = eager_step()
         sync()
     elapsed = time.perf_counter() - t0
-    from news_recommendation_model_amd import ops as _ops
     _ops.check_index_errors(dev)               # a clamped table index / user id would make the number meaningless: fail loudly
     if not (args.graph or args.no_kernel_timing):
         events, native.kernel_events, native.kernel_event_tags = native.kernel_events, None, None
         # heavy kernels: timed region; everything else: the 3 bracketed warm-up steps
         events = events + [e for e in table_events if e[0] not in HEAVY]
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if use_dist:
+        # every rank's own time for the K steps (stragglers show here); the job's time is the slowest rank's
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in allr]
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -661,6 +726,18 @@ def main():
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
+        # whole-step roofline: the matrix FLOPs one step ISSUES on the MFMA pipe (attention contractions + every dense GEMM incl.
+        # side projections and weight gradients; algorithmic 2MNK, no tile padding; x3 for the bf16x3 split) / ms_per_step / peak
+        issue = 3.0 if args.dtype == "bf16x3" else 1.0
+        step_roof = None
+        if flop_meter is not None:
+            mf = issue * (flop_meter["dense"] + flop_meter["contraction"])
+            step_roof = {"matrix_flops_per_step": mf, "contraction_flops": issue * flop_meter["contraction"],
+                         "dense_flops": issue * flop_meter["dense"], "contraction_launches": flop_meter["contraction_launches"],
+                         "gemm_launches": flop_meter["dense_launches"], "issue_factor": issue, "peak": peak, "unit": "TFLOP/s",
+                         "achieved": round(mf / (ms * 1e-3) / 1e12, 2), "frac": round(mf / (ms * 1e-3) / 1e12 / peak, 4),
+                         "ms_at_peak": round(mf / (peak * 1e12) * 1e3, 3)}
+        roof["step"] = step_roof
         line = {
             "metric": "train impressions/sec", "value": round(world * B * args.steps / elapsed, 2),
             "unit": "impressions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -669,19 +746,23 @@ def main():
                       "bf16x3": "bf16x3 (attention contractions and dense GEMMs: bf16 MFMA on hi/lo split operands, fp32 accumulate; rest f32)"}[args.dtype],
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: EBNeRD-large-shape synthetic" if args.workload == "C3-large" else args.workload,
-                       "per_gpu_batch": B, "global_batch": world * B, "hist": H, "candidates": T, "emb": D,
+                       "per_gpu_batch": B, "global_batch": world * B, "resident_batches_per_gpu": NB, "hist": H, "candidates": T, "emb": D,
                        "user_num": user_num, "parallelism": f"dp{world}", "attention_streams": 2 if (inv.uses_two_streams(B * T * H * D) and not args.timed_kernel_events) else 1,
                        "weight_gradient_stream": bool(_ops._wgrad["streams"]) and not args.timed_kernel_events,
                        "kernel_durations_from": "timed region (event pairs on the launch stream)" if args.timed_kernel_events else "3 extra eager one-stream steps after the warm-up", "launch": "hipGraph replay" if args.graph else "eager",
                        "step": "fwd+loss+bwd+allreduce+Adam(wd=1e-5)" if use_dist else "fwd+loss+bwd+Adam(wd=1e-5)"},
-            "loss": round(float(loss), 6),
+            "loss": round(float(loss), 6), "first_step_loss": round(first_step_loss, 6),
+            "loss_note": f"first_step_loss: initial weights, batch 0 (the oracle's value for its sample of the same batch: cpu_baseline."
+                         f"hip_vs_oracle_first_step.oracle_loss); loss: last timed step, after {counter['i']} steps cycling {NB} resident batches",
+            "launch_probe": probe, "per_rank_ms_per_step": {"min": round(min(per_rank_ms), 3), "max": round(max(per_rank_ms), 3),
+                                                            "ranks": [round(x, 3) for x in per_rank_ms]},
             "roofline": dict(roof, traffic=traffic, traffic_source=traffic_note),
             "kernels": {k: {"launches": v["launches"], "mean_ms": round(v["mean_ms"], 4)} for k, v in kern.items()},
             "grad_allreduce_bytes": opt.nbytes if use_dist else 0, "replicas_in_sync": replicas_in_sync,
             "collective": (dict({"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                  "all_reduce_per_step": 1, "launcher": "self (child processes)" if os.environ.get("NRM_BENCH_CHILD") else "external",
                                  "devices": devices, "devices_distinct": len({(d["uuid"], d["pci"]) for d in devices}) == world},
-                                **collective_stats(opt, world))
+                                **collective_stats(opt, world, table_collective_events))
                            if use_dist else None),
         }
         if pcie is not None:

@@ -217,6 +217,28 @@ def packed_weights_generation():
     return _packs.generation
 
 
+# Matrix-FLOP meter (bench.py's whole-step roofline): while enabled, every GEMM / contraction launch adds its ALGORITHMIC FLOPs
+# (2 M N K; no tile padding, no bf16x3 issue factor) under "dense" or "contraction".
+_flop_meter = None
+
+
+def flop_meter_start():
+    global _flop_meter
+    _flop_meter = {"dense": 0.0, "contraction": 0.0, "dense_launches": 0, "contraction_launches": 0}
+
+
+def flop_meter_stop():
+    global _flop_meter
+    m, _flop_meter = _flop_meter, None
+    return m
+
+
+def _count_flops(kind, flops):
+    if _flop_meter is not None:
+        _flop_meter[kind] += float(flops)
+        _flop_meter[kind + "_launches"] += 1
+
+
 import os as _os
 _FORCE_F32_GEMM = _os.environ.get("NRM_GEMM_F32") == "1"        # diagnostics: every dense / side GEMM on the fp32 kernels
 
@@ -243,6 +265,7 @@ def _gemm_nt(x, w_src, row_stride, col_stride, n_out, k_red, bias, epilogue, z=N
     y = torch.empty(M, ldy, dtype=torch.float32, device=x.device)
     if epilogue in (EPI_GELU, EPI_MUL):
         z = torch.empty(M, ldy, dtype=torch.float32, device=x.device)
+    _count_flops("dense", 2.0 * M * n_out * k_red)
     native.call("nrm_gemm_nt", native.ptr(x), x.stride(0), M, native.ptr(packed), n_out, k_red,
                 native.ptr(bias) if bias is not None else None, native.ptr(y), ldy,
                 native.ptr(z) if z is not None else None, z.stride(0) if z is not None else 0,
@@ -263,6 +286,7 @@ def _gemm_tn_slabs(a, b, want_colsum, zero_out=None, mma=None):
     ldws = _pad4(ni)
     ws = torch.empty(nsplit, nj, ldws, dtype=torch.float32, device=a.device)
     cs = torch.empty(nsplit, ldws, dtype=torch.float32, device=a.device) if want_colsum else None
+    _count_flops("dense", 2.0 * R * ni * nj)
     native.call("nrm_gemm_tn", native.ptr(a), a.stride(0), ni, native.ptr(b), b.stride(0), nj, R,
                 native.ptr(ws), ldws, native.ptr(cs) if cs is not None else None,
                 native.ptr(zero_out) if zero_out is not None else None, zero_out.numel() if zero_out is not None else 0,
@@ -454,6 +478,7 @@ def _pwattn_fwd_impl(t, h, w1, b1, w2, b2, save_z, mma):
     native.call("nrm_pwattn_pack_wp", native.ptr(w1), 4 * D, D, mma, native.ptr(packed), st)
     s = torch.empty(B, T, H, dtype=torch.float32, device=t.device)
     z = torch.empty((B, T, H, D) if save_z else (0,), dtype=torch.float32, device=t.device)
+    _count_flops("contraction", 2.0 * B * T * H * D * D)
     native.call("nrm_pwattn_fwd", native.ptr(t), native.ptr(h), native.ptr(u), native.ptr(v),
                 native.ptr(packed), native.ptr(w2v), native.ptr(b2),
                 native.ptr(z) if save_z else None, native.ptr(s), B, T, H, D, mma, st)
@@ -540,8 +565,10 @@ def _attn_bwd_core(ds, t, h, w1, w2, z, mma, need_dt=True, need_dh=True, acc=Non
             # (one of the two unwanted: the kernel forms both anyway; the unwanted one goes to a scratch buffer)
             dt_ = dt if need_dt else torch.empty(B, T, D, dtype=torch.float32, device=dev)
             dh_ = dh if need_dh else torch.empty(B, H, D, dtype=torch.float32, device=dev)
+            _count_flops("contraction", 2.0 * B * T * H * D * D)
             native.call("nrm_pwattn_bwd_rw_dtdh", native.ptr(dz), native.ptr(t), native.ptr(h), native.ptr(img), native.ptr(dt_),
                         native.ptr(dh_), B, T, H, D, mma, st, tag="pwattn_bwd_rw_dtdh")
+        _count_flops("contraction", 2.0 * B * T * H * D * D)
         native.call("nrm_pwattn_bwd_contract", native.ptr(dz), native.ptr(t), native.ptr(h), native.ptr(wp), 4 * D, None, None,
                     native.ptr(wsp), B, T, H, D, 4, mma, DZ_HL4, st, tag="pwattn_bwd_e_bt")
     else:
@@ -551,6 +578,7 @@ def _attn_bwd_core(ds, t, h, w1, w2, z, mma, need_dt=True, need_dh=True, acc=Non
         for passes, tag in ((1, "pwattn_bwd_e_bt") if need_dt else (4, "pwattn_bwd_e_dw"), (2, "pwattn_bwd_e_bh")):
             if passes == 2 and not need_dh:
                 continue
+            _count_flops("contraction", 2.0 * B * T * H * D * D)
             native.call("nrm_pwattn_bwd_contract", native.ptr(dz), native.ptr(t), native.ptr(h),
                         native.ptr(wp), 4 * D, native.ptr(dt) if need_dt else None, native.ptr(dh) if need_dh else None,
                         native.ptr(wsp), B, T, H, D, passes, mma, DZ_F32, st, tag=tag)

@@ -329,7 +329,9 @@ class GraphedTrainStep:
     (reference default dimensions: 3.1 -> 2.7 ms).  New data is copied INTO the tensors
     of ``batch`` before ``replay()``; ``loss`` / ``out`` are overwritten in place by every replay."""
 
-    def __init__(self, model, optimizer, batch, alpha=0.95, warmup=3):
+    def __init__(self, model, optimizer, batch, alpha=0.95, warmup=3, pool=None):
+        """``pool``: the memory pool of another GraphedTrainStep (``other.graph.pool()``) -- several captured steps, e.g. one per
+        resident input batch, then share their intermediates' memory (they must be replayed one at a time, in any order)."""
         if not isinstance(optimizer, FlatAdam):
             raise TypeError("GraphedTrainStep needs trainer.FlatAdam (its step counter lives on the device)")
         from . import native
@@ -343,7 +345,7 @@ class GraphedTrainStep:
                 train_step(model, optimizer, batch, None, alpha)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, pool=pool):
             self.loss, self.out = train_step(model, optimizer, batch, None, alpha)
 
     def replay(self):

@@ -83,29 +83,41 @@ def instant_interest_grad_bounds(sd, batch):
     fixture and of the fp32 oracle against the float64 gradient is 1e-7 .. 1.3e-6 of S, while |gradient| / S is 0.05 .. 0.25
     for the weight and 1e-4 .. 1e-3 for the bias -- so a zeroed gradient fails for both.
     Returns {II_W: S [8,3], II_B: S [8]} (float64 numpy)."""
+    return oracle_step_with_bounds(sd, batch)[3]
+
+
+def oracle_step_with_bounds(sd, batch, dtype=None):
+    """One forward + loss + backward of the oracle (train-mode BatchNorm, no optimizer) -> (loss, r, {key: gradient}, bounds of
+    instant_interest_grad_bounds), all from ONE pass.  ``dtype``: float64 (default; error analysis) or float32 -- the S sums are
+    magnitudes, so an fp32 pass serves as well where a second pass is too expensive (B = 256 at C3 dimensions)."""
     import torch
     from oracle import user_model_oracle as orc
-    p = orc.to_torch_params(sd, dtype=torch.float64)
+    dtype = dtype or torch.float64
+    p = orc.to_torch_params(sd, dtype=dtype)
     tb = {k: torch.from_numpy(np.asarray(v)) for k, v in batch.items() if isinstance(v, np.ndarray) and v.ndim > 0}
-    with orc.precision(torch.float64):
+    with orc.precision(dtype):
         r, aux = orc.user_model_forward(p, tb["x_history"], tb["x_target"], tb["x_global"], training=True, bn_state=None,
                                         return_aux=True)
         aux["eu_L"].retain_grad()
         aux["c"].retain_grad()
-        orc.user_model_loss(p, tb["user_id"], r, tb["label"]).backward()
+        loss = orc.user_model_loss(p, tb["user_id"], r, tb["label"])
+        loss.backward()
     n = aux["eu_L"].shape[-1]
     c0 = aux["eu_H"].shape[-1]                                   # concat order [eu_H | eu_L | ec] (user_model.py:31)
     cols = slice(c0, c0 + n)
     mask = (aux["eu_L"].detach().reshape(-1, n) > 0).double()
-    de = aux["eu_L"].grad.reshape(-1, n).abs()
-    dc = aux["c"].grad[:, cols]
-    gamma, beta = p["bn.weight"].detach()[cols], p["bn.bias"].detach()[cols]
-    chat = (aux["c"].detach()[:, cols] - beta) / gamma
-    rstd = 1.0 / torch.sqrt(aux["bn_var"].detach()[cols] + 1e-5)
+    de = aux["eu_L"].grad.reshape(-1, n).abs().double()
+    dc = aux["c"].grad[:, cols].double()
+    gamma, beta = p["bn.weight"].detach()[cols].double(), p["bn.bias"].detach()[cols].double()
+    chat = (aux["c"].detach()[:, cols].double() - beta) / gamma
+    rstd = 1.0 / torch.sqrt(aux["bn_var"].detach()[cols].double() + 1e-5)
     term = de + rstd * gamma.abs() * (dc.abs() + dc.abs().mean(0, keepdim=True) + chat.abs() * (dc * chat).abs().mean(0, keepdim=True))
     term = mask * term
     x = tb["x_global"].reshape(-1, tb["x_global"].shape[-1]).double().abs()
-    return {II_W: (term.T @ x).numpy(), II_B: term.sum(0).numpy()}
+    bounds = {II_W: (term.T @ x).numpy(), II_B: term.sum(0).numpy()}
+    grads = {k: (v.grad.detach().numpy() if v.grad is not None else np.zeros(tuple(v.shape), dtype=np.float32))
+             for k, v in p.items() if k not in orc.BUFFER_KEYS}
+    return float(loss.detach()), r.detach().numpy(), grads, bounds
 
 
 def grad_tolerance(key, ref, grad_tol, bounds=None, full=True):

@@ -81,6 +81,9 @@ def test_bench_self_launches_two_ranks(lib, tmp_path):
     assert c["allreduce_ms"] > 0 and c["allreduce_events"] == 3 and c["bus_GBps"] > 0
     assert abs(c["bus_GBps"] - 2 * (2 - 1) / 2 * line["grad_allreduce_bytes"] / (c["allreduce_ms"] * 1e-3) / 1e9) < 0.02 * c["bus_GBps"] + 0.01
     assert len(c["devices"]) == 2 and {d["rank"] for d in c["devices"]} == {0, 1} and c["devices_distinct"] is False
+    # round 4: every rank's own time (stragglers), and gloo cannot be captured -> the launch-mode probe leaves the step eager
+    pr_ = line["per_rank_ms_per_step"]
+    assert len(pr_["ranks"]) == 2 and pr_["min"] <= pr_["max"] <= line["ms_per_step"] * 1.001 and line["config"]["launch"] == "eager"
 
 
 def test_bench_refuses_ranks_that_share_a_device(lib, tmp_path):
@@ -101,32 +104,49 @@ def test_bench_refuses_ranks_that_share_a_device(lib, tmp_path):
     assert any("not distinct" in o for o in outs), outs[0][-1500:]
 
 
-def test_bench_one_rank_through_rccl(lib, tmp_path):
-    """RCCL itself under the data-parallel step, as far as a one-GPU box can take it: a process group of ONE rank with
-    backend nccl (NRM_DIST_WORLD1=1), so the communicator, the in-stream all-reduce of the flat gradient (ReduceOp.AVG),
-    the barrier-bracketed timing and the replica check of bench.py all run through librccl on the code path of N > 1."""
-    env = dict(os.environ, NRM_DIST_WORLD1="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "NRM_DIST_BACKEND", "NRM_SINGLE_DEVICE"):
-        env.pop(k, None)
+def _bench_line(env, *extra):
     pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                         "--workload", "ref-default", "--batch", "16", "--no-cpu-baseline"],
+                         "--workload", "ref-default", "--batch", "16", "--no-cpu-baseline", *extra],
                         env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
     assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-3000:]
     lines = [ln for ln in pr.stdout.decode().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, pr.stdout.decode()[-2000:]
-    line = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_one_rank_through_rccl(lib, tmp_path):
+    """RCCL itself under the data-parallel step, as far as a one-GPU box can take it: a process group of ONE rank with
+    backend nccl (NRM_DIST_WORLD1=1), so the communicator, the in-stream all-reduce of the flat gradient (ReduceOp.AVG),
+    the barrier-bracketed timing and the replica check of bench.py all run through librccl on the code path of N > 1 --
+    eagerly, as a CAPTURED step with the all-reduce inside the HIP graph (what `--gpus N` now probes and
+    may choose), and through the default launch-mode probe."""
+    env = dict(os.environ, NRM_DIST_WORLD1="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "NRM_DIST_BACKEND", "NRM_SINGLE_DEVICE"):
+        env.pop(k, None)
+    line = _bench_line(env, "--eager")
     assert line["collective"]["backend"] == "nccl" and line["collective"]["world_size"] == 1
     assert line["grad_allreduce_bytes"] > 0 and line["replicas_in_sync"] is True
-    assert line["config"]["launch"] == "eager"
-    # the one-rank average must leave the step itself unchanged: same loss as the run without a process group
+    assert line["config"]["launch"] == "eager" and line["collective"]["allreduce_events"] == 3
+    assert line["per_rank_ms_per_step"]["min"] == line["per_rank_ms_per_step"]["max"] == line["per_rank_ms_per_step"]["ranks"][0]
+    # the captured step with the in-stream all-reduce inside the graph
+    env["MASTER_PORT"] = str(_free_port())
+    graphed = _bench_line(env, "--graph")
+    assert graphed["config"]["launch"] == "hipGraph replay" and graphed["collective"]["backend"] == "nccl"
+    assert graphed["replicas_in_sync"] is True and graphed["first_step_loss"] == line["first_step_loss"]
+    assert graphed["collective"]["allreduce_timed_in"].startswith("3 eager") and graphed["collective"]["allreduce_ms"] > 0
+    # the default: both modes probed over >= 10 steps each and reported; this launch-bound shape takes the captured step
+    env["MASTER_PORT"] = str(_free_port())
+    probed = _bench_line(env)
+    pb = probed["launch_probe"]
+    assert pb["steps"] >= 10 and pb["t_eager_ms"] > 0 and pb["t_graph_ms"] > 0
+    assert probed["config"]["launch"] == "hipGraph replay" and probed["replicas_in_sync"] is True
+    # the one-rank average must leave the step itself unchanged: same losses as the run without a process group
     env.pop("NRM_DIST_WORLD1")
-    pr2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                          "--workload", "ref-default", "--batch", "16", "--no-cpu-baseline", "--eager"],
-                         env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
-    assert pr2.returncode == 0, pr2.stderr.decode(errors="replace")[-3000:]
-    line2 = json.loads([ln for ln in pr2.stdout.decode().splitlines() if ln.startswith("{")][0])
+    line2 = _bench_line(env, "--eager")
+    assert line2["collective"] is None
     assert abs(line["loss"] - line2["loss"]) <= 1e-5 * max(1.0, abs(line2["loss"]))
+    assert abs(line["first_step_loss"] - line2["first_step_loss"]) <= 1e-6 * max(1.0, abs(line2["first_step_loss"]))
 
 
 def test_bench_line_carries_the_contract_fields(lib, tmp_path):
@@ -154,5 +174,12 @@ def test_bench_line_carries_the_contract_fields(lib, tmp_path):
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    # round 4: the whole-step roofline, the first step's loss next to the last one's, the resident batches the steps cycle through
+    st = r["step"]
+    assert st["matrix_flops_per_step"] == st["contraction_flops"] + st["dense_flops"] > 0 and st["contraction_launches"] == 5
+    assert abs(st["frac"] - st["matrix_flops_per_step"] / (d["ms_per_step"] * 1e-3) / 1e12 / st["peak"]) < 1e-3
+    assert d["config"]["resident_batches_per_gpu"] == 4 and d["first_step_loss"] > 0 and "loss" in d
+    chk = d["cpu_baseline"]["hip_vs_oracle_first_step"]
+    assert chk["loss_rel_err"] < 1e-3 and chk["logit_max_rel_err"] < 1e-3 and chk["oracle_loss"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and c["unit"] == d["unit"]
