@@ -35,7 +35,7 @@ static const int kTargetWaves = 2048;
 static const int kBtWaves = 6144;
 static const int kBtMinGroups = 96;     // groups per split of the dt/dW pass (each split = one [D, D] slab of dW_p)
 static const int kBhWaves = 12288;
-static const int kTnWaves = 4096;      // gemm_tn (dW = dY^T X): NRM_TN_WAVES overrides
+static const int kTnWaves = 0;         // gemm_tn (dW = dY^T X): 0 = one round of wave tasks at the chosen kernel's occupancy (gemm_tn_plan); NRM_TN_WAVES overrides
 
 static int check_dims(const char* fn, int B, int T, int H, int D) {
     if (B < 0 || T <= 0 || H <= 0 || D <= 0) return fail(NRM_EINVAL, "%s: B=%d T=%d H=%d D=%d must be positive", fn, B, T, H, D);
@@ -52,7 +52,7 @@ extern "C" {
 
 int nrm_abi_version(void) { return NRM_ABI_VERSION; }
 int nrm_build_flags(void) { return nrm::pwattn_fwd_diag_flags() | nrm::pwattn_fwd_rw_diag_flags() | nrm::pwattn_bwd_diag_flags() |
-                                    nrm::pwattn_bwd_rw_diag_flags() | nrm::gemm_bf16_diag_flags(); }
+                                    nrm::pwattn_bwd_rw_diag_flags() | nrm::gemm_bf16_diag_flags() | nrm::gemm_diag_flags(); }
 const char* nrm_last_error(void) { return g_err; }
 
 long nrm_pwattn_packed_floats(int D) {
@@ -267,7 +267,7 @@ int nrm_gemm_nt(const float* x, int ldx, int M, const float* packed, int N, int 
     p.rows = pl.rows; p.bias = bias; p.N = N; p.y = y; p.ldy = ldy;
     p.z = epilogue == NRM_EPI_BIAS ? nullptr : z; p.ldz = epilogue == NRM_EPI_BIAS ? 4 : ldz;
     p.m = epilogue == NRM_EPI_MUL ? m : nullptr; p.ldm = epilogue == NRM_EPI_MUL ? ldm : 4;
-    p.M = M; p.kchunks = (K + 15) / 16;
+    p.M = M; p.kchunks = (K + 15) / 16; p.K = K;
     return check_hip(nrm::gemm_nt_launch(p, pl, epilogue, (hipStream_t)stream), "gemm_nt");
 }
 

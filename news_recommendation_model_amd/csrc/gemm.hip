@@ -12,8 +12,14 @@
 //             memory into MFMA operand registers (one dword per lane per tile, ping-pong prefetch), the row
 //             range is split over waves and every wave stores one partial slab (transposed: [K][N]).
 #include <cstdlib>
+#include <type_traits>
 #include "common.hpp"
 #include "gemm.hpp"
+// timing diagnostics only (scripts/_diag): results are WRONG with any bit set -- 1: no barrier in the K loop of gemm_nt,
+// 2: gemm_nt without its epilogue stores, 4: gemm_nt DMAs only its first K-chunk, 8: gemm_tn never reloads its operands
+#ifndef NRM_DIAG_GEMM
+#define NRM_DIAG_GEMM 0
+#endif
 
 namespace nrm {
 
@@ -156,7 +162,10 @@ __global__ __launch_bounds__(256, WPE) void gemm_nt_kernel(const GemmNtParams p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(buf + (WROWS + (wave * MT + j) * 16) * 16),
                                                      16, voff_x[j], c * 64, 0, 0);
     };
-    auto compute = [&](const float* buf) {
+    // FULL = false: column tiles >= ntv (the zero padding of the last N-chunk: 3 of 13 tiles at N = 1608) and K-steps >= ks (the
+    // zero padding of the last K-chunk: 3 of 4 steps at K = 402) issue no MFMA -- 3 % of the launch each at those widths
+    auto compute = [&](const float* buf, auto full, int ntv, int ks) {
+        constexpr bool FULL = decltype(full)::value;
         const float* Xl = buf + WROWS * 16;
         f32x4 pf[MT];
 #pragma unroll
@@ -166,28 +175,46 @@ __global__ __launch_bounds__(256, WPE) void gemm_nt_kernel(const GemmNtParams p)
         for (int it = 0; it < NT; ++it) {
             f32x4 afn = af;
             if (it + 1 < NT) afn = *reinterpret_cast<const f32x4*>(&buf[((it + 1) * 16 + r16) * 16 + rslot]);
+            if (FULL || it < ntv) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
+                    if (FULL || j < ks)
 #pragma unroll
-                for (int jt = 0; jt < MT; ++jt) acc[it][jt] = mfma16(af[j], pf[jt][j], acc[it][jt]);
+                        for (int jt = 0; jt < MT; ++jt) acc[it][jt] = mfma16(af[j], pf[jt][j], acc[it][jt]);
+            }
             __builtin_amdgcn_sched_barrier(0);
             af = afn;
         }
     };
 
+    const int nt_valid = min(NT, (p.N - n0 + 15) >> 4);              // (workgroup-uniform)
+    const int klast = min(4, (p.K - 16 * (p.kchunks - 1) + 3) >> 2);
     dma_chunk(0, smem);
     __syncthreads();
-    for (int c = 0; c < p.kchunks; ++c) {
-        float* cur = smem + (c & 1) * BUF;
-        float* nxt = smem + ((c & 1) ^ 1) * BUF;
-        if (c + 1 < p.kchunks) dma_chunk(c + 1, nxt);
-        compute(cur);
-        __syncthreads();
+    if (nt_valid == NT) {
+        for (int c = 0; c + 1 < p.kchunks; ++c) {
+            float* cur = smem + (c & 1) * BUF;
+            float* nxt = smem + ((c & 1) ^ 1) * BUF;
+            if (!(NRM_DIAG_GEMM & 4)) dma_chunk(c + 1, nxt);
+            compute(cur, std::true_type{}, NT, 4);
+            if (!(NRM_DIAG_GEMM & 1)) __syncthreads();
+        }
+        compute(smem + ((p.kchunks - 1) & 1) * BUF, std::false_type{}, NT, klast);
+    } else {
+        for (int c = 0; c < p.kchunks; ++c) {
+            float* cur = smem + (c & 1) * BUF;
+            float* nxt = smem + ((c & 1) ^ 1) * BUF;
+            if (c + 1 < p.kchunks && !(NRM_DIAG_GEMM & 4)) dma_chunk(c + 1, nxt);
+            compute(cur, std::false_type{}, nt_valid, c + 1 < p.kchunks ? 4 : klast);
+            if (!(NRM_DIAG_GEMM & 1)) __syncthreads();
+        }
     }
+    if (NRM_DIAG_GEMM & 2) return;
 
     // epilogue: lane holds out[m = m0 + (wave*MT+jt)*16 + r16][n = n0 + 16 it + 4q .. +3]
 #pragma unroll
     for (int it = 0; it < NT; ++it) {
+        if (it < nt_valid) {
         const int n = n0 + it * 16 + 4 * q;
         const int nb = (n0 + it * 16) * 4;
         f32x4 bb = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -222,6 +249,7 @@ __global__ __launch_bounds__(256, WPE) void gemm_nt_kernel(const GemmNtParams p)
                 for (int e = 0; e < 4; ++e) g[e] = acc[it][jt][e] * gelu_grad_f(zz[e]);
                 if (n < p.ldy) store_b128_guarded(__builtin_bit_cast(u32x4, g), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb);
             }
+        }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -292,8 +320,44 @@ hipError_t gemm_nt_launch(const GemmNtParams& p, const GemmNtPlan& pl, int epi, 
 // ---------------------------------------------------------------------------------------------
 // gemm_tn: every wave owns a (KT*16 i) x (DT*16 j) tile of C[i,j] = sum_r A[r,i] B[r,j] and a row range.
 // slab layout: ws[split][j][ldws] (transposed, float4 along i);  colsum[split][i] = sum_r A[r,i] (tiles j0 == 0).
+//
+// Column layout of an operand block of W MFMA tiles (W in {2, 4, 5, 8}; as in the backward contractions, pwattn_bwd.hip
+// tile_col): fragment index r (0..15) of tile t is block column
+//     W = 2:  2 r + t            (one  8-byte load per lane and reduction step)
+//     W = 4:  4 r + t            (one 16-byte load)
+//     W = 5:  4 r + t | 64 + r   (16 + 4 bytes)
+//     W = 8:  4 r + t | 64 + 4 r + (t - 4)      (two 16-byte loads)
+// so a lane's loads feed W MFMA operands without any shuffle.  Round 4 added W = 2 and 8: the head's weight gradients are
+// 26 x 101 tiles of 16 (402 x 1608), which 4 x 4 wave tiles cover with 10.4 % padding and 2 x 8 with 3 % (13 x 13 exactly
+// in i); w1's 25 x 26 tiles are exact in 5 x 2.
+template <int W> __device__ __forceinline__ int tn_col(int t, int r) {
+    if (W == 2) return 2 * r + t;
+    if (W == 5 && t == 4) return 64 + r;
+    if (W == 8 && t >= 4) return 64 + 4 * r + (t - 4);
+    return 4 * r + t;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int W> __device__ __forceinline__ void tn_load(float (&v)[W], const __amdgpu_buffer_rsrc_t rs, unsigned vlo, unsigned vhi, int soff) {
+    if constexpr (W == 2) {
+        const auto x = __builtin_amdgcn_raw_buffer_load_b64(rs, vlo, soff, 0);
+        v[0] = __uint_as_float(x[0]); v[1] = __uint_as_float(x[1]);
+    } else {
+        const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rs, vlo, soff, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __uint_as_float(x[e]);
+        if constexpr (W == 5) v[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vhi, soff, 0));
+        if constexpr (W == 8) {
+            const u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(rs, vhi, soff, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 + e] = __uint_as_float(y[e]);
+        }
+    }
+}
+#endif
+constexpr int tn_waves_per_simd(int KT, int DT) { return KT * DT <= 16 ? 4 : 3; }      // 64 accumulator VGPRs: 4 waves; 100: 3
+
 template <int KT, int DT>
-__global__ __launch_bounds__(256, KT == 4 ? 4 : 3) void gemm_tn_kernel(const GemmTnParams p) {
+__global__ __launch_bounds__(256, tn_waves_per_simd(KT, DT)) void gemm_tn_kernel(const GemmTnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -328,11 +392,9 @@ __global__ __launch_bounds__(256, KT == 4 ? 4 : 3) void gemm_tn_kernel(const Gem
         const_cast<float*>(p.A) + (size_t)r_lo * p.lda, 0, nrows > 0 ? ((nrows - 1) * p.lda + p.acols) * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.B) + (size_t)r_lo * p.ldb, 0, nrows > 0 ? ((nrows - 1) * p.ldb + p.bcols) * 4 : 0, 0x00020000);
-    // Column layout as in the backward contractions (pwattn_bwd.hip, tile_col): lane (r16, q) holds columns
-    // 4*r16 + tile of tiles 0..3 and column 64 + r16 of tile 4, so one 16-byte load per lane feeds four MFMA operands
-    // (2 + 2 vector-memory instructions per reduction step instead of 5 + 5).
-    const unsigned va4 = (unsigned)(q * p.lda + i0 + 4 * r16) * 4u, va1 = (unsigned)(q * p.lda + i0 + 64 + r16) * 4u;
-    const unsigned vb4 = (unsigned)(q * p.ldb + j0 + 4 * r16) * 4u, vb1 = (unsigned)(q * p.ldb + j0 + 64 + r16) * 4u;
+    // lane (r16, q) reads reduction row q of a step; low / high part of its columns (tn_col)
+    const unsigned va_lo = (unsigned)(q * p.lda + i0 + tn_col<KT>(0, r16)) * 4u, va_hi = (unsigned)(q * p.lda + i0 + tn_col<KT>(KT - 1, r16) - (KT == 8 ? 3 : 0)) * 4u;
+    const unsigned vb_lo = (unsigned)(q * p.ldb + j0 + tn_col<DT>(0, r16)) * 4u, vb_hi = (unsigned)(q * p.ldb + j0 + tn_col<DT>(DT - 1, r16) - (DT == 8 ? 3 : 0)) * 4u;
     const int astep = p.lda * 16, bstep = p.ldb * 16;
 
     f32x4 C[KT][DT];
@@ -343,23 +405,15 @@ __global__ __launch_bounds__(256, KT == 4 ? 4 : 3) void gemm_tn_kernel(const Gem
     // four operand register sets: operands are requested three reduction steps ahead of their MFMAs
     float a0[KT], b0[DT], a1[KT], b1[DT], a2[KT], b2[DT], a3[KT], b3[DT];
     auto load_step = [&](float (&a)[KT], float (&b)[DT], int s) {
-        const u32x4 xa = __builtin_amdgcn_raw_buffer_load_b128(ra, va4, s * astep, 0);
-        const u32x4 xb = __builtin_amdgcn_raw_buffer_load_b128(rb, vb4, s * bstep, 0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { a[e] = __uint_as_float(xa[e]); b[e] = __uint_as_float(xb[e]); }
-        if (KT > 4) a[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, va1, s * astep, 0));
-        if (DT > 4) b[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, vb1, s * bstep, 0));
+        tn_load<KT>(a, ra, va_lo, va_hi, s * astep);
+        tn_load<DT>(b, rb, vb_lo, vb_hi, s * bstep);
     };
     auto mfma_batch = [&](const float (&a)[KT], const float (&b)[DT]) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it)                                  // fed by the two 16-byte loads
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) C[it][jt] = mfma16(a[it], b[jt], C[it][jt]);
 #pragma unroll
         for (int it = 0; it < KT; ++it) {
             cs[it] += a[it];
 #pragma unroll
-            for (int jt = (it < 4 ? 4 : 0); jt < DT; ++jt) C[it][jt] = mfma16(a[it], b[jt], C[it][jt]);
+            for (int jt = 0; jt < DT; ++jt) C[it][jt] = mfma16(a[it], b[jt], C[it][jt]);
         }
     };
 #pragma unroll
@@ -370,6 +424,7 @@ __global__ __launch_bounds__(256, KT == 4 ? 4 : 3) void gemm_tn_kernel(const Gem
     if (1 < nsteps) load_step(a1, b1, 1);
     if (2 < nsteps) load_step(a2, b2, 2);
     for (int s = 0; s < nsteps; s += 4) {
+        if (NRM_DIAG_GEMM & 8) { mfma_batch(a0, b0); mfma_batch(a1, b1); mfma_batch(a2, b2); mfma_batch(a0, b0); continue; }
         if (s + 3 < nsteps) load_step(a3, b3, s + 3);
         mfma_batch(a0, b0);
         if (s + 1 < nsteps) {
@@ -386,41 +441,66 @@ __global__ __launch_bounds__(256, KT == 4 ? 4 : 3) void gemm_tn_kernel(const Gem
         }
     }
 
-    // lane holds C[it][jt][e] = c[i0 + tile_col(it, 4q+e)][j0 + tile_col(jt, r16)]; the slab is transposed (ws[split][j][i])
+    // lane holds C[it][jt][e] = c[i0 + tn_col<KT>(it, 4q+e)][j0 + tn_col<DT>(jt, r16)]; the slab is transposed (ws[split][j][i]),
+    // and every store below is a float4 of four consecutive i
     float* wsp = p.ws + (size_t)split * p.ncols_j * p.ldws;
 #pragma unroll
     for (int jt = 0; jt < DT; ++jt) {
-        const int j = j0 + (jt < 4 ? 4 * r16 + jt : 64 + r16);
+        const int j = j0 + tn_col<DT>(jt, r16);
         if (j >= p.ncols_j) continue;
         float* row = wsp + (size_t)j * p.ldws + i0;
+        if constexpr (KT == 2) {
+            // i = 8 q + 2 e + it
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int ii = 16 * q + 4 * e;
-            if (i0 + ii < p.ldws) *reinterpret_cast<f32x4*>(row + ii) = f32x4{C[0][jt][e], C[1][jt][e], C[2][jt][e], C[3][jt][e]};
+            for (int h = 0; h < 2; ++h) {
+                const int ii = 8 * q + 4 * h;
+                if (i0 + ii < p.ldws) *reinterpret_cast<f32x4*>(row + ii) = f32x4{C[0][jt][2 * h], C[1][jt][2 * h], C[0][jt][2 * h + 1], C[1][jt][2 * h + 1]};
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < (KT == 8 ? 2 : 1); ++g)                 // blocks of four tiles: i = 64 g + 16 q + 4 e + (it - 4 g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ii = 64 * g + 16 * q + 4 * e;
+                    if (i0 + ii < p.ldws)
+                        *reinterpret_cast<f32x4*>(row + ii) = f32x4{C[4 * g][jt][e], C[4 * g + 1][jt][e], C[4 * g + 2][jt][e], C[4 * g + 3][jt][e]};
+                }
+            if constexpr (KT == 5)
+                if (i0 + 64 + 4 * q < p.ldws) *reinterpret_cast<f32x4*>(row + 64 + 4 * q) = C[KT - 1][jt];     // i = 64 + 4 q + e
         }
-        if (KT > 4 && i0 + 64 + 4 * q < p.ldws) *reinterpret_cast<f32x4*>(row + 64 + 4 * q) = C[KT - 1][jt];
     }
     if (p.colsum && tj == 0) {
 #pragma unroll
         for (int it = 0; it < KT; ++it) {
             const float v = sum_rows4(cs[it]);
-            const int i = i0 + (it < 4 ? 4 * r16 + it : 64 + r16);
+            const int i = i0 + tn_col<KT>(it, r16);
             if (q == 0 && i < p.ldws) p.colsum[(size_t)split * p.ldws + i] = v;
         }
     }
 #endif
 }
 
+// wave-tile shapes the fp32 kernel is built for, in order of preference (fewer loads per MFMA first)
+static const int kTnShapes[][2] = {{4, 4}, {5, 5}, {2, 8}, {8, 2}, {5, 2}, {2, 5}};
+
 GemmTnPlan gemm_tn_plan(int ncols_i, int ncols_j, int R, int target_waves, int mma) {
     GemmTnPlan pl;
     const int ni16 = (ncols_i + 15) / 16, nj16 = (ncols_j + 15) / 16;
-    // 5x5 or 4x4 tiles of 16: the shape with fewer padded tiles
-    const long w5 = (long)((ni16 + 4) / 5) * ((nj16 + 4) / 5) * 25, w4 = (long)((ni16 + 3) / 4) * ((nj16 + 3) / 4) * 16;
-    pl.T = w5 <= w4 ? 5 : 4;
-    if (mma) pl.T = 4;                              // bf16 forms (gemm_bf16.hip): 4x4 tiles, 32-row super-steps
-    pl.nti = (ni16 + pl.T - 1) / pl.T;
-    pl.ntj = (nj16 + pl.T - 1) / pl.T;
+    // the shape with the fewest padded MFMA tiles (ties: the earlier entry)
+    pl.KT = pl.DT = 4;
+    long best = -1;
+    static const bool wide = [] { const char* e = getenv("NRM_TN_SHAPES"); return !(e && e[0] == '0'); }();      // 0: 4x4 / 5x5 only (round 3)
+    for (int k = 0; k < (mma ? 1 : (wide ? 6 : 2)); ++k) {          // bf16 forms (gemm_bf16.hip): 4x4 tiles, 32-row super-steps
+        const int kt = kTnShapes[k][0], dt = kTnShapes[k][1];
+        const long w = (long)((ni16 + kt - 1) / kt) * kt * ((nj16 + dt - 1) / dt) * dt;
+        if (best < 0 || w < best) { best = w; pl.KT = kt; pl.DT = dt; }
+    }
+    pl.nti = (ni16 + pl.KT - 1) / pl.KT;
+    pl.ntj = (nj16 + pl.DT - 1) / pl.DT;
     const int tiles = pl.nti * pl.ntj;
+    // one round of wave tasks at the kernel's occupancy (4 waves per SIMD with <= 64 accumulator registers, else 3): with
+    // 4096 tasks on the 3072 slots of the 5x5 kernel a third of the chip ran a second round alone
+    if (target_waves <= 0) target_waves = 1024 * (mma ? 1 : tn_waves_per_simd(pl.KT, pl.DT));
     int ns = target_waves / tiles / 4 * 4;
     if (ns < 4) ns = 4;
     // at least 128 rows per split: every split costs a [ncols_j x ldws] partial slab that is written and read back by the
@@ -439,8 +519,16 @@ GemmTnPlan gemm_tn_plan(int ncols_i, int ncols_j, int R, int target_waves, int m
 hipError_t gemm_tn_launch(GemmTnParams p, const GemmTnPlan& pl, hipStream_t st) {
     p.nti = pl.nti; p.nsplit = pl.nsplit; p.rps = pl.rps;
     const dim3 grid(pl.nti * pl.ntj, (pl.nsplit + 3) / 4), block(256);
-    if (pl.T == 5) hipLaunchKernelGGL((gemm_tn_kernel<5, 5>), grid, block, 0, st, p);
-    else           hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), grid, block, 0, st, p);
+    const int shape = pl.KT * 16 + pl.DT;
+    switch (shape) {
+        case 4 * 16 + 4: hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), grid, block, 0, st, p); break;
+        case 5 * 16 + 5: hipLaunchKernelGGL((gemm_tn_kernel<5, 5>), grid, block, 0, st, p); break;
+        case 2 * 16 + 8: hipLaunchKernelGGL((gemm_tn_kernel<2, 8>), grid, block, 0, st, p); break;
+        case 8 * 16 + 2: hipLaunchKernelGGL((gemm_tn_kernel<8, 2>), grid, block, 0, st, p); break;
+        case 5 * 16 + 2: hipLaunchKernelGGL((gemm_tn_kernel<5, 2>), grid, block, 0, st, p); break;
+        case 2 * 16 + 5: hipLaunchKernelGGL((gemm_tn_kernel<2, 5>), grid, block, 0, st, p); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
@@ -564,5 +652,7 @@ hipError_t slab_reduce_multi_launch(const SlabReduceParams* ps, int n, hipStream
     }
     return hipSuccess;
 }
+
+int gemm_diag_flags() { return NRM_DIAG_GEMM ? 0x100 : 0; }
 
 }  // namespace nrm

@@ -15,6 +15,7 @@ struct GemmNtParams {
     float* z; int ldz;                    // EPI_GELU: pre-activation out, EPI_DGELU: pre-activation in, EPI_MUL: un-multiplied out
     const float* m; int ldm;              // EPI_MUL: y = (x W^T + bias) * m   (the gate of user_model.py:33)
     int M, kchunks;
+    int K;                                // reduction width (kchunks = ceil(K / 16); columns K.. of the last chunk are zero padding)
 };
 struct GemmNtPlan { int NT, MT, nchunks, rows; };
 GemmNtPlan gemm_nt_plan(int N);
@@ -52,7 +53,7 @@ struct GemmTnParams {
     int R, ncols_j;
     int nti, nsplit, rps;                 // filled by gemm_tn_launch from the plan
 };
-struct GemmTnPlan { int T, nti, ntj, nsplit, rps; };
+struct GemmTnPlan { int KT, DT, nti, ntj, nsplit, rps; };      // wave tile = (KT*16 i) x (DT*16 j); target_waves <= 0: one round at the kernel's occupancy
 GemmTnPlan gemm_tn_plan(int ncols_i, int ncols_j, int R, int target_waves, int mma = 0);
 hipError_t gemm_tn_launch(GemmTnParams p, const GemmTnPlan& pl, hipStream_t st);
 hipError_t gemm_tn_bf16_launch(GemmTnParams p, const GemmTnPlan& pl, int mma, hipStream_t st);      // gemm_bf16.hip
@@ -70,5 +71,6 @@ hipError_t slab_reduce_launch(const SlabReduceParams& p, hipStream_t st);
 constexpr int SLAB_MAX = 24;              // slab sets per multi launch (the table is a kernel argument: 24 x 96 B + 4 x 96 B + 4)
 struct SlabTable { SlabReduceParams e[SLAB_MAX]; int spc[SLAB_MAX]; int nchunk[SLAB_MAX]; int gx[SLAB_MAX]; int first[SLAB_MAX]; int n; };
 hipError_t slab_reduce_multi_launch(const SlabReduceParams* ps, int n, hipStream_t st);
+int gemm_diag_flags();
 
 }  // namespace nrm

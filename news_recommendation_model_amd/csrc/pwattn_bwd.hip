@@ -15,6 +15,7 @@
 //      row receives one contiguous float-atomic add per k-range (5 at D=400).
 //   The side-projection gradients (from du, dv) are plain GEMMs done by the caller.
 #include <cstdlib>
+#include <type_traits>
 #ifndef NRM_PIPE_SGB
 #define NRM_PIPE_SGB 1
 #endif
@@ -195,9 +196,170 @@ __global__ __launch_bounds__(256) void bwd_dz_kernel(float* __restrict__ z, cons
     }
 }
 
+// Full-row form of the same pass (round 4).  The slab form above cuts every 1600-byte row (D = 400) into four 400-byte
+// segments that straddle 128-byte lines and belong to four workgroups: 4.25 TB/s of algorithmic bytes at C3, against 5.1-5.2
+// for D = 384 / 512 with the same kernel.  Here ONE workgroup of 512 threads owns all D columns of an impression: a (b,t)
+// block of H rows is one contiguous, 128-byte-aligned range (H * D * 4 = 80 000 bytes = 625 whole lines at C3), every wave
+// access is 1 KiB contiguous, and no line is shared between workgroups.  nx = D/4 float4 columns x ny = 512/nx row slots; a
+// thread owns rows h = ty + ny * k (k < 2 RC) of every candidate, so du (sum over t) is a REGISTER accumulator per owned
+// row -- no [H][nx] LDS slab (80 KB at C3, which had kept this form at one workgroup per CU when round 3 sized it) -- and
+// dv (sum over h) is the register sum over the thread's rows plus one LDS exchange per candidate, as above.  A candidate is
+// processed in two chunks of RC rows per thread: while chunk c is computed the loads of the next chunk are in flight
+// (buffers A / B), which keeps the kernel at <= 128 VGPRs = two workgroups (16 waves) per CU.
+template <int THREADS, int RC, int NCH>
+__global__ __launch_bounds__(THREADS, 4) void bwd_dz_rows_kernel(float* __restrict__ z, const float* __restrict__ ds,
+                                                             const float* __restrict__ w2, float* __restrict__ dw2,
+                                                             float* __restrict__ db2, float* __restrict__ du, float* __restrict__ dv,
+                                                             int T, int H, int D, int fmt) {
+    static_assert(NCH % 3 == 0, "three operand buffers rotate once or twice per candidate");
+    __shared__ __attribute__((aligned(16))) f32x4 red[2 * THREADS];
+    const int nx = D >> 2, ny = THREADS / nx;
+    const int tid = threadIdx.x;
+    const int ty = tid / nx, tx = tid - ty * nx;
+    const int b = blockIdx.x;
+    const int col = 4 * tx;
+    const bool act = ty < ny;
+    const f32x4 w = act ? *reinterpret_cast<const f32x4*>(w2 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 dur[NCH * RC];
+#pragma unroll
+    for (int k = 0; k < NCH * RC; ++k) dur[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 aw = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ab = 0.f;
+    const bool sum_ds = db2 != nullptr && tx == 0;
+    // one buffer descriptor per workgroup (base = the impression's first row): 32-bit offsets, rows past T*H read 0
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(z + (size_t)b * T * H * D, 0, (unsigned)((size_t)T * H * D * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ds) + (size_t)b * T * H, 0, (unsigned)(T * H * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+
+    f32x4 zb[3][RC];
+    float gb[3][RC];
+    auto load_rows = [&](int t, int c, f32x4 (&zz)[RC], float (&g)[RC]) {
+#pragma unroll
+        for (int u = 0; u < RC; ++u) {
+            const int h = ty + ny * (c * RC + u);
+            const bool ok = act && t < T && h < H;
+            const unsigned row = (unsigned)(t * H + h);
+            g[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, ok ? row * 4u : OOB, 0, 0));
+            zz[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, ok ? (row * (unsigned)D + (unsigned)col) * 4u : OOB, 0, 0));
+        }
+    };
+    auto compute_rows = [&](int t, int c, const f32x4 (&zz)[RC], const float (&g)[RC], f32x4 (&acc)[RC], f32x4& av) {
+#pragma unroll
+        for (int u = 0; u < RC; ++u) {
+            const int h = ty + ny * (c * RC + u);
+            if (act && h < H) {
+                f32x4 dz;
+                if (sum_ds) ab += g[u];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const GeluParts gp = gelu_parts(zz[u][e]);
+                    aw[e] = fmaf(g[u] * zz[u][e], gp.cdf, aw[e]);                          // ds * gelu(z)
+                    dz[e] = g[u] * w[e] * fmaf(zz[u][e] * 0.39894228040143267794f, gp.e, gp.cdf);
+                }
+                const unsigned off = ((unsigned)(t * H + h) * (unsigned)D + (unsigned)col) * 4u;
+                if (fmt) {                                                                  // NRM_DZ_HL4 (see the slab form)
+                    unsigned short hi[4], lo[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const __bf16 hb = (__bf16)dz[e];
+                        const __bf16 lb = (__bf16)(dz[e] - (float)hb);
+                        hi[e] = __builtin_bit_cast(unsigned short, hb);
+                        lo[e] = __builtin_bit_cast(unsigned short, lb);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        u32x4{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16),
+                              (unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16)}, rz, off, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dz), rz, off, 0, 0);
+                }
+                av += dz;
+                acc[u] += dz;
+            }
+        }
+    };
+    auto finish = [&](int t, const f32x4& av) {
+        f32x4* ex = red + (t & 1) * THREADS;                         // double-buffered: one barrier per candidate
+        ex[tid] = av;
+        __syncthreads();
+        if (ty == 0) {
+            f32x4 sum = ex[tx];
+            for (int y = 1; y < ny; ++y) sum += ex[y * nx + tx];
+            *reinterpret_cast<f32x4*>(dv + ((long)b * T + t) * D + col) = sum;
+        }
+    };
+    // loads run two chunks ahead of the arithmetic: chunk (t, c) lives in buffer c % 3 (NCH % 3 == 0: the same buffer for the
+    // same c of every candidate, so every index below is a compile-time constant after unrolling)
+    load_rows(0, 0, zb[0], gb[0]);
+    load_rows(0, 1, zb[1], gb[1]);
+    f32x4 (*durc)[RC] = reinterpret_cast<f32x4(*)[RC]>(dur);
+    for (int t = 0; t < T; ++t) {
+        f32x4 av = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int cn = (c + 2) % NCH, tn = t + (c + 2) / NCH;
+            load_rows(tn, cn, zb[(c + 2) % 3], gb[(c + 2) % 3]);     // (masked past the last candidate and past the last row)
+            compute_rows(t, c, zb[c % 3], gb[c % 3], durc[c], av);
+        }
+        finish(t, av);
+    }
+    if (act)
+#pragma unroll
+        for (int k = 0; k < NCH * RC; ++k) {
+            const int h = ty + ny * k;
+            if (h < H) *reinterpret_cast<f32x4*>(du + ((long)b * H + h) * D + col) = dur[k];
+        }
+    __syncthreads();
+    red[tid] = aw;
+    __syncthreads();
+    if (ty == 0) {
+        f32x4 sum = red[tx];
+        for (int y = 1; y < ny; ++y) sum += red[y * nx + tx];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(dw2 + col + e, sum[e]);
+    }
+    if (db2 != nullptr) {
+        __syncthreads();
+        float* redf = reinterpret_cast<float*>(red);
+        if (tx == 0 && act) redf[ty] = ab;
+        __syncthreads();
+        if (tid == 0) {
+            float sum = 0.f;
+            for (int y = 0; y < ny; ++y) sum += redf[y];
+            atomicAdd(db2, sum);
+        }
+    }
+}
+
+// The full-row form applies when the workgroup's threads are well used (nx * ny of them own columns), a thread's rows fit 6
+// register accumulators (512 threads, two workgroups per CU; else 1024 threads, one per CU: the 12-row form of 512 threads
+// spills at 128 VGPRs), one impression's z block fits 32-bit byte offsets, and there are workgroups for every CU twice over;
+// NRM_DZ_ROWS=0 / 1 forces the slab / the full-row form.  Returns the workgroup size (0: slab form) and the rows per thread.
+static int dz_rows_threads(int B, int T, int H, int D, int& rows) {
+    const char* env = getenv("NRM_DZ_ROWS");                         // (read per launch: tests switch forms inside one process)
+    const int forced = env ? (env[0] == '0' ? 0 : 1) : -1;
+    if (forced == 0 || D % 4 || D > 2048 || (size_t)T * H * D * 4 >= (1ull << 31)) return 0;
+    const int nx = D >> 2;
+    for (int threads = 512; threads <= 1024; threads *= 2) {
+        const int ny = threads / nx;
+        if (ny < 1) continue;
+        rows = (H + ny - 1) / ny;
+        if (rows > 6) continue;
+        if (forced != 1 && (nx * ny * 20 < threads * 17 || B < 512)) continue;   // >= 85 % of the lanes own a column; work for every CU
+        return threads;
+    }
+    return 0;
+}
+
 hipError_t bwd_dz_launch(float* z, const float* ds, const float* w2, float* dw2, float* db2, float* du, float* dv,
                          int B, int T, int H, int D, int dz_format, hipStream_t st) {
     if (B <= 0) return hipSuccess;
+    int rows = 0;
+    if (const int threads = dz_rows_threads(B, T, H, D, rows)) {
+        auto kern = threads == 512 ? (rows <= 3 ? bwd_dz_rows_kernel<512, 1, 3> : bwd_dz_rows_kernel<512, 2, 3>)
+                                   : (rows <= 3 ? bwd_dz_rows_kernel<1024, 1, 3> : bwd_dz_rows_kernel<1024, 2, 3>);
+        hipLaunchKernelGGL(kern, dim3(B), dim3(threads), 0, st, z, ds, w2, dw2, db2, du, dv, T, H, D, dz_format);
+        return hipGetLastError();
+    }
     int nslab = (D + 127) / 128;
     int slab_cols = ((D + nslab - 1) / nslab + 3) / 4 * 4;           // equal slabs (D = 400: 4 x 100 columns)
     // Long histories: a candidate's rows fit ONE sweep of the workgroup (the path that requests the next candidate's rows before

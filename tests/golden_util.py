@@ -125,7 +125,8 @@ def grad_tolerance(key, ref, grad_tol, bounds=None, full=True):
     plus -- for the two instant-interest tensors -- II_NOISE * S per entry (instant_interest_grad_bounds)."""
     tol = grad_tol * float(np.abs(ref).max()) + 1e-9
     if bounds is not None and key in bounds:
-        tol = tol + II_NOISE * pick(bounds[key], full)
+        b = pick(bounds[key], full)
+        tol = tol + II_NOISE * (b.reshape(np.shape(ref)) if b.size == np.size(ref) else b)
     return tol
 
 

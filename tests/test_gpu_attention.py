@@ -83,6 +83,34 @@ def test_scores_and_grads_match_oracle(lib, B, T, H, D):
         assert rel_err(got[k], ref[k]) < GRAD_TOL, k
 
 
+# full-row form of the dz pass (bwd_dz_rows_kernel: one workgroup owns all D columns of an impression; default only for B >= 512,
+# i.e. reached by the full-size tests alone): forced here on the small shapes it can take -- (D, H) -> 512 threads with <= 6 rows
+# per thread, else 1024 threads; shapes it cannot take (D = 768 / H = 128: 26 rows per thread) silently stay on the slab form
+DZ_ROWS_SHAPES = [(2, 30, 50, 400), (2, 30, 32, 256), (2, 15, 200, 64), (2, 20, 10, 256), (3, 7, 19, 72), (1, 1, 1, 64), (5, 1, 3, 64),
+                  (7, 5, 37, 100), (1, 5, 17, 388), (1, 4, 9, 420), (2, 5, 7, 66), (3, 2, 4, 5), (1, 3, 300, 64), (2, 2, 520, 8),
+                  (1, 64, 128, 768), (4, 3, 6, 1024), (2, 31, 5, 16)]
+
+
+@pytest.mark.parametrize("mma", ["f32", "bf16x3"])
+@pytest.mark.parametrize("B,T,H,D", DZ_ROWS_SHAPES)
+def test_full_row_dz_pass_matches_oracle_and_slab_form(lib, monkeypatch, mma, B, T, H, D):
+    rng = np.random.default_rng(B * 1000 + T * 100 + H * 10 + D)
+    w = _weights(rng, D)
+    tgt = rng.standard_normal((B, T, D)).astype(np.float32)
+    his = rng.standard_normal((B, H, D)).astype(np.float32)
+    gs = rng.standard_normal((B, T, H)).astype(np.float32)
+    monkeypatch.setenv("NRM_DZ_ROWS", "0")
+    _, slab, _, _ = _run_both(w, tgt, his, gs, mma=mma)
+    monkeypatch.setenv("NRM_DZ_ROWS", "1")
+    s, got, s_ref, ref = _run_both(w, tgt, his, gs, mma=mma)
+    fwd_tol, grad_tol = (FWD_TOL, GRAD_TOL) if mma == "f32" else (1e-4, 1e-3)
+    assert rel_err(s, s_ref) < fwd_tol
+    for k in ref:
+        assert rel_err(got[k], ref[k]) < grad_tol, (k, rel_err(got[k], ref[k]))
+        # same arithmetic per element; only the order of the dv / dw2 partial sums (and of float atomics downstream) differs
+        assert rel_err(got[k], slab[k]) < 2e-5, (k, rel_err(got[k], slab[k]))
+
+
 # bf16 MFMA operands, fp32 accumulation (BASELINE config 2).  Gates are the same as for the fp32 path and are taken against
 # the SAME fp32 oracle: forward <= 1e-3, gradients <= 1e-2 (max-abs difference over max-abs reference, per tensor).
 BF16_SHAPES = [

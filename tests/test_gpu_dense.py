@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("M,K,N", [(300, 402, 1608), (257, 1608, 402), (64, 3, 8), (1000, 402, 1), (33, 66, 64),
-                                   (5, 272, 68), (192, 400, 400)])
+                                   (5, 272, 68), (192, 400, 400), (700, 402, 400), (700, 400, 402), (3000, 1608, 402), (1300, 402, 1608)])
 @pytest.mark.parametrize("gelu", [False, True])
 def test_linear_forward_backward(lib, M, K, N, gelu):
     from news_recommendation_model_amd import ops
@@ -59,6 +59,30 @@ def test_mlp_gelu_forward_backward(lib, M, K, Hd, N):
     assert rel_err(y.detach().cpu().numpy(), y_ref.detach().numpy()) < 1e-5
     for a, r, name in zip(dev, ref, ("x", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")):
         assert rel_err(a.grad.cpu().numpy(), r.grad.numpy()) < 1e-5, name
+
+
+@pytest.mark.parametrize("R,ni,nj,shape", [(1000, 30, 125, (2, 8)), (1000, 125, 30, (8, 2)), (999, 78, 30, (5, 2)), (1001, 30, 78, (2, 5)),
+                                           (2051, 402, 1608, (2, 8)), (2051, 1608, 402, (8, 2)), (640, 400, 402, (5, 2)), (640, 402, 400, (2, 5)),
+                                           (515, 400, 400, (5, 5)), (515, 64, 64, (4, 4)), (3, 402, 1608, (2, 8)), (130, 2, 1608, (2, 8))])
+def test_gemm_tn_wave_tile_shapes(lib, R, ni, nj, shape):
+    """dW = dY^T X on every wave-tile shape of gemm_tn (round 4: 2x8 / 8x2 / 5x2 / 2x5 beside 4x4 / 5x5, chosen by padding:
+    csrc/gemm.hip tn_col) against float64: ragged widths, ragged row counts, several row splits, column sums."""
+    from news_recommendation_model_amd import native, ops
+    g = torch.Generator(device="cpu").manual_seed(R + 3 * ni + 5 * nj)
+    a = ops._rows(torch.randn(R, ni, generator=g).cuda())
+    b = ops._rows(torch.randn(R, nj, generator=g).cuda())
+    # the plan really is the shape under test (16-column tiles: the fewest padded tiles win)
+    t = lambda n, w: -(-(-(-n // 16)) // w) * w                     # noqa: E731
+    cands = [(4, 4), (5, 5), (2, 8), (8, 2), (5, 2), (2, 5)]
+    costs = [t(ni, k) * t(nj, d) for k, d in cands]
+    assert cands[costs.index(min(costs))] == shape
+    c, cs = ops._gemm_tn(a, b, True)
+    torch.cuda.synchronize()
+    ref = a.double().t() @ b.double()
+    assert tuple(c.shape) == (ni, nj)
+    assert rel_err(c.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    assert rel_err(cs.cpu().numpy(), a.double().sum(0).cpu().numpy()) < 1e-5
+    assert native.load().nrm_gemm_tn_nsplit(ni, nj, R, 0) >= 1
 
 
 def test_linear_accepts_strided_and_3d_inputs(lib):

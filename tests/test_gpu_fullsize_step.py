@@ -97,6 +97,7 @@ def test_full_size_c3_train_step_big_batch_paths_match_their_small_batch_forms(l
         return m, trainer.FlatAdam(m)
 
     def grads_of_first_step(m, opt, defer):
+        bn_before = {k: v.clone() for k, v in m.bn.state_dict().items()}
         out = m(tb["x_history"], tb["x_target"], tb["x_global"])
         loss = m.loss(tb["user_id"], out, tb["label"])
         if defer:
@@ -108,7 +109,7 @@ def test_full_size_c3_train_step_big_batch_paths_match_their_small_batch_forms(l
         torch.cuda.synchronize()
         g = {k: opt.grad_view(i).clone() for i, (k, _) in enumerate(m.named_parameters())}
         opt.zero_grad()
-        m.bn.reset_running_stats()
+        m.bn.load_state_dict(bn_before)                      # no optimizer step was taken: the model is as built again
         return out.detach().clone(), float(loss.detach()), g
 
     # (a) the default paths of a big batch: counting sort, weight-gradient stream, two attention streams, deferred reductions
@@ -158,9 +159,9 @@ def test_full_size_c3_train_step_big_batch_paths_match_their_small_batch_forms(l
                 continue
             move = float((ps - p0[k]).norm())
             assert float((po - ps).norm()) <= 2e-2 * move + 1e-7, (k, float((po - ps).norm()), move)
-    for other in (big, graphed):
-        assert torch.allclose(other.bn.running_mean, small.bn.running_mean, rtol=1e-4, atol=1e-6)
-        assert torch.allclose(other.bn.running_var, small.bn.running_var, rtol=1e-4, atol=1e-7)
+    for other in (big, graphed):          # four updates of the running statistics (norm-wise: tiny entries follow the weights' sign noise)
+        assert rel_err(other.bn.running_mean.cpu().numpy(), small.bn.running_mean.cpu().numpy()) < 1e-3
+        assert rel_err(other.bn.running_var.cpu().numpy(), small.bn.running_var.cpu().numpy()) < 1e-3
 
 
 def test_c3_first_train_step_at_batch_256_matches_the_oracle(lib, monkeypatch):
