@@ -267,7 +267,7 @@ int nrm_gemm_nt(const float* x, int ldx, int M, const float* packed, int N, int 
     p.rows = pl.rows; p.bias = bias; p.N = N; p.y = y; p.ldy = ldy;
     p.z = epilogue == NRM_EPI_BIAS ? nullptr : z; p.ldz = epilogue == NRM_EPI_BIAS ? 4 : ldz;
     p.m = epilogue == NRM_EPI_MUL ? m : nullptr; p.ldm = epilogue == NRM_EPI_MUL ? ldm : 4;
-    p.M = M; p.kchunks = (K + 15) / 16; p.K = K;
+    p.M = M; p.kchunks = (K + 15) / 16;
     return check_hip(nrm::gemm_nt_launch(p, pl, epilogue, (hipStream_t)stream), "gemm_nt");
 }
 

@@ -162,9 +162,11 @@ __global__ __launch_bounds__(256, WPE) void gemm_nt_kernel(const GemmNtParams p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(buf + (WROWS + (wave * MT + j) * 16) * 16),
                                                      16, voff_x[j], c * 64, 0, 0);
     };
-    // FULL = false: column tiles >= ntv (the zero padding of the last N-chunk: 3 of 13 tiles at N = 1608) and K-steps >= ks (the
-    // zero padding of the last K-chunk: 3 of 4 steps at K = 402) issue no MFMA -- 3 % of the launch each at those widths
-    auto compute = [&](const float* buf, auto full, int ntv, int ks) {
+    // FULL = false: column tiles >= ntv -- the zero padding of the last N-chunk (3 of 13 tiles at N = 1608, 1 of 13 at N = 400) --
+    // issue no MFMA: 3-4 % of the launch at those widths.  (The zero padding of the last K-chunk cannot be skipped the same way:
+    // K-step j of a chunk covers k = 4 q + j over the four lane groups q -- the 16-byte fragment layout -- so at K = 402 every
+    // step of the last chunk still holds k = 400 or 401.)
+    auto compute = [&](const float* buf, auto full, int ntv) {
         constexpr bool FULL = decltype(full)::value;
         const float* Xl = buf + WROWS * 16;
         f32x4 pf[MT];
@@ -178,9 +180,8 @@ __global__ __launch_bounds__(256, WPE) void gemm_nt_kernel(const GemmNtParams p)
             if (FULL || it < ntv) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (FULL || j < ks)
 #pragma unroll
-                        for (int jt = 0; jt < MT; ++jt) acc[it][jt] = mfma16(af[j], pf[jt][j], acc[it][jt]);
+                    for (int jt = 0; jt < MT; ++jt) acc[it][jt] = mfma16(af[j], pf[jt][j], acc[it][jt]);
             }
             __builtin_amdgcn_sched_barrier(0);
             af = afn;
@@ -188,26 +189,15 @@ __global__ __launch_bounds__(256, WPE) void gemm_nt_kernel(const GemmNtParams p)
     };
 
     const int nt_valid = min(NT, (p.N - n0 + 15) >> 4);              // (workgroup-uniform)
-    const int klast = min(4, (p.K - 16 * (p.kchunks - 1) + 3) >> 2);
     dma_chunk(0, smem);
     __syncthreads();
-    if (nt_valid == NT) {
-        for (int c = 0; c + 1 < p.kchunks; ++c) {
-            float* cur = smem + (c & 1) * BUF;
-            float* nxt = smem + ((c & 1) ^ 1) * BUF;
-            if (!(NRM_DIAG_GEMM & 4)) dma_chunk(c + 1, nxt);
-            compute(cur, std::true_type{}, NT, 4);
-            if (!(NRM_DIAG_GEMM & 1)) __syncthreads();
-        }
-        compute(smem + ((p.kchunks - 1) & 1) * BUF, std::false_type{}, NT, klast);
-    } else {
-        for (int c = 0; c < p.kchunks; ++c) {
-            float* cur = smem + (c & 1) * BUF;
-            float* nxt = smem + ((c & 1) ^ 1) * BUF;
-            if (c + 1 < p.kchunks && !(NRM_DIAG_GEMM & 4)) dma_chunk(c + 1, nxt);
-            compute(cur, std::false_type{}, nt_valid, c + 1 < p.kchunks ? 4 : klast);
-            if (!(NRM_DIAG_GEMM & 1)) __syncthreads();
-        }
+    for (int c = 0; c < p.kchunks; ++c) {
+        float* cur = smem + (c & 1) * BUF;
+        float* nxt = smem + ((c & 1) ^ 1) * BUF;
+        if (c + 1 < p.kchunks && !(NRM_DIAG_GEMM & 4)) dma_chunk(c + 1, nxt);
+        if (nt_valid == NT) compute(cur, std::true_type{}, NT);
+        else compute(cur, std::false_type{}, nt_valid);
+        if (!(NRM_DIAG_GEMM & 1)) __syncthreads();
     }
     if (NRM_DIAG_GEMM & 2) return;
 

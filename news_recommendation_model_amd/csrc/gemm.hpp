@@ -15,7 +15,6 @@ struct GemmNtParams {
     float* z; int ldz;                    // EPI_GELU: pre-activation out, EPI_DGELU: pre-activation in, EPI_MUL: un-multiplied out
     const float* m; int ldm;              // EPI_MUL: y = (x W^T + bias) * m   (the gate of user_model.py:33)
     int M, kchunks;
-    int K;                                // reduction width (kchunks = ceil(K / 16); columns K.. of the last chunk are zero padding)
 };
 struct GemmNtPlan { int NT, MT, nchunks, rows; };
 GemmNtPlan gemm_nt_plan(int N);
