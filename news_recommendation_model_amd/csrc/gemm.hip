@@ -17,6 +17,9 @@
 #include "gemm.hpp"
 // timing diagnostics only (scripts/_diag): results are WRONG with any bit set -- 1: no barrier in the K loop of gemm_nt,
 // 2: gemm_nt without its epilogue stores, 4: gemm_nt DMAs only its first K-chunk, 8: gemm_tn never reloads its operands
+#ifndef NRM_PRIO
+#define NRM_PRIO 0        // tuning: s_setprio level of the K loops (0: none)
+#endif
 #ifndef NRM_DIAG_GEMM
 #define NRM_DIAG_GEMM 0
 #endif
@@ -191,6 +194,7 @@ __global__ __launch_bounds__(256, WPE) void gemm_nt_kernel(const GemmNtParams p)
     const int nt_valid = min(NT, (p.N - n0 + 15) >> 4);              // (workgroup-uniform)
     dma_chunk(0, smem);
     __syncthreads();
+    if (NRM_PRIO) __builtin_amdgcn_s_setprio(NRM_PRIO);
     for (int c = 0; c < p.kchunks; ++c) {
         float* cur = smem + (c & 1) * BUF;
         float* nxt = smem + ((c & 1) ^ 1) * BUF;
@@ -199,6 +203,7 @@ __global__ __launch_bounds__(256, WPE) void gemm_nt_kernel(const GemmNtParams p)
         else compute(cur, std::false_type{}, nt_valid);
         if (!(NRM_DIAG_GEMM & 1)) __syncthreads();
     }
+    if (NRM_PRIO) __builtin_amdgcn_s_setprio(0);
     if (NRM_DIAG_GEMM & 2) return;
 
     // epilogue: lane holds out[m = m0 + (wave*MT+jt)*16 + r16][n = n0 + 16 it + 4q .. +3]

@@ -16,6 +16,9 @@
 //   The side-projection gradients (from du, dv) are plain GEMMs done by the caller.
 #include <cstdlib>
 #include <type_traits>
+#ifndef NRM_PRIO
+#define NRM_PRIO 0        // tuning: s_setprio level of the MFMA phases (0: none)
+#endif
 #ifndef NRM_PIPE_SGB
 #define NRM_PIPE_SGB 1
 #endif
@@ -613,6 +616,7 @@ __global__ __launch_bounds__(256, (MMA && KT > 4) || (MMA == 2 && WITH_DW && WIT
                 for (int jt = (it < 4 ? 4 : 0); jt < DT; ++jt) E[it][jt] = mfma16(a[it], b[jt], E[it][jt]);
         };
         if (!BF16) {
+        if (NRM_PRIO) __builtin_amdgcn_s_setprio(NRM_PRIO);           // reduction steps above the co-resident wave's epilogue
         // step 0 accumulates onto an inline-constant 0 (no accumulator clearing)
 #pragma unroll
         for (int it = 0; it < 4; ++it)
@@ -643,6 +647,7 @@ __global__ __launch_bounds__(256, (MMA && KT > 4) || (MMA == 2 && WITH_DW && WIT
             // those registers let the W_p^T reads run two tiles ahead of their FMAs instead of being waited one by one
             if (!AHEAD && nsteps > 1) load_step(a1, b1, 1);
         }
+        if (NRM_PRIO) __builtin_amdgcn_s_setprio(0);
         }
 
         // epilogue: lane holds E[k = k0 + tile_col(it, 4q+e)][d = d0 + tile_col(jt, r16)]; the LDS image of W_p^T is

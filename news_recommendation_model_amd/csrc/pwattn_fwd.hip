@@ -23,6 +23,9 @@
 #ifndef NRM_DIAG_FWD
 #define NRM_DIAG_FWD 0        // bit 0: no accumulator-init loads, bit 1: no K-chunk DMA after the first, bit 2: no z store,
 #endif                        // bit 3: no GELU / fc2 dot (plain sum instead)
+#ifndef NRM_PRIO
+#define NRM_PRIO 0        // tuning: s_setprio level of the K loops (0: none)
+#endif
 #include "common.hpp"
 #include "pwattn.hpp"
 
@@ -188,6 +191,7 @@ __global__ __launch_bounds__(256, WPE) void pwattn_fwd_kernel(const FwdParams p)
         // (__syncthreads() waits for this wave's DMA -- vmcnt(0) -- before the barrier).
         dma_chunk(0, smem);
         __syncthreads();
+        if (NRM_PRIO) __builtin_amdgcn_s_setprio(NRM_PRIO);           // MFMA phase above the co-resident waves' epilogues / accumulator loads
         for (int c = 0; c < p.kchunks; ++c) {
             float* cur = smem + (c & 1) * BUF;
             float* nxt = smem + ((c & 1) ^ 1) * BUF;
@@ -195,6 +199,7 @@ __global__ __launch_bounds__(256, WPE) void pwattn_fwd_kernel(const FwdParams p)
             compute(cur);
             __syncthreads();
         }
+        if (NRM_PRIO) __builtin_amdgcn_s_setprio(0);
 
         // --- epilogue of this N-chunk: optional z store ; GELU ; partial fc2 dot
 #pragma unroll
