@@ -172,6 +172,8 @@ int nrm_pwattn_bwd_contract(const float* dz, const float* t, const float* h, con
         // absorbing the re-reads); small groups keep the blocked walk.  NRM_BT_INTERLEAVE=0|1 forces either (tests).
         p.interleave = (long)p.R * D * (long)sizeof(float) > (256L << 10);
         if (const char* e = getenv("NRM_BT_INTERLEAVE")) p.interleave = atoi(e);
+        p.order = 0;
+        if (const char* e = getenv("NRM_BT_ORDER")) p.order = atoi(e);
         if (int rc = check_hip(nrm::bwd_e_launch(p, pl, true, mma, (hipStream_t)stream), "bwd_e pass 1")) return rc;
     }
     // pass 2: groups (b,h); rows r = t.  X_g = dz[b,:,h,:], Y_g = t[b];  out = dh

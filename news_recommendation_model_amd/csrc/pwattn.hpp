@@ -50,6 +50,7 @@ struct BwdEParams {
     int interleave;                       // serial kernel: the 4 waves of a workgroup walk one group range round-robin
     int x_hl4;                            // X is in the NRM_DZ_HL4 format (bf16 forms only): no conversion of the dz operand
     int with_dt;                          // 0: the (b,t)-grouped pass only accumulates dW_p (dt comes from pwattn_bwd_rw.hip)
+    int order;                            // serial kernel, block order inside an XCD: 0 = (split group, k-range, d-column), 1 = (k-range, split group, d-column)
 };
 struct BwdEPlan { int DT, KT, ndcol, nkw, nsplit, gps; };
 BwdEPlan bwd_e_plan(int D, int G, int target_waves, int min_gps = 1, int mma = 0);

@@ -450,9 +450,21 @@ __global__ __launch_bounds__(256, (MMA && KT > 4) || (MMA == 2 && WITH_DW && WIT
     const int lin = blockIdx.y * gridDim.x + blockIdx.x;
     const int xq = nblk >> 3, xr = nblk & 7, xcd = lin & 7;         // bijective for any nblk
     const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+    // order 1 (big groups, C5): k-range-major -- an XCD then holds few k-ranges (nkw / 8 of them), so the dz columns it streams
+    // are ITS columns: every dz byte is fetched by one XCD only, and its co-resident workgroups (a k-range's d-columns of a few
+    // split groups) share each dz slice while it is hot.  With order 0 the ndcol * nkw tile kinds of one split group exceed the
+    // XCD's resident workgroups (144 kinds against 64 at D = 768), so the kinds run in batches and every batch streams the
+    // groups' history rows again.
     const int dcol = logical % p.ndcol;
-    const int kw = (logical / p.ndcol) % p.nkw;
-    const int sgrp = logical / (p.ndcol * p.nkw);
+    int kw, sgrp;
+    if (p.order == 1) {
+        const int nsg = nblk / (p.ndcol * p.nkw);
+        sgrp = (logical / p.ndcol) % nsg;
+        kw = logical / (p.ndcol * nsg);
+    } else {
+        kw = (logical / p.ndcol) % p.nkw;
+        sgrp = logical / (p.ndcol * p.nkw);
+    }
     const int d0 = dcol * (DT * 16);
     const int k0 = kw * (KT * 16);
 
