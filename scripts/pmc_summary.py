@@ -4,7 +4,7 @@ kernel-stats CSV + summary, per-kernel PMC means, the HBM-traffic figures bench.
 summary is stamped with the sha256 of the kernel sources it measured (build.sources_digest(); bench.py refuses to quote a
 traffic figure whose stamp differs from the sources it runs) and with the commit they belong to.
 
-usage: python scripts/pmc_summary.py <tag> [round]      files are named r<round>_<tag>_*      (round defaults to 3)"""
+usage: python scripts/pmc_summary.py <tag> [round]      files are named r<round>_<tag>_*      (round defaults to 4)"""
 import collections
 import csv
 import glob
@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 from news_recommendation_model_amd import build          # noqa: E402
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "c3"
-rnd = sys.argv[2] if len(sys.argv) > 2 else "3"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "4"
 src = f"gpurun_out/prof_{tag}"
 pre = f"profiles/r{rnd}_{tag}"
 head = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
@@ -78,7 +78,7 @@ e_kernels = sorted((k for k in out if k.startswith("bwd_e_kernel")), key=lambda 
 dw = next((k for k in e_kernels if k.endswith(", 0, false, false>")), None)
 bt = pick("bwd_dw_r32_kernel") or next((k for k in e_kernels if k != dw and (", true, true" in k or ", true, false" in k)), None)   # dW_p-only form (bf16), or the WITH_DW instantiation = the (b,t) pass
 bh = pick("bwd_e_pipe_kernel") or next((k for k in e_kernels if k not in (bt, dw)), None)
-names = {"nrm_pwattn_fwd": fwd, "nrm_pwattn_bwd_dz": pick("bwd_dz_kernel"), "pwattn_bwd_e_bt": bt, "pwattn_bwd_e_dw": dw, "pwattn_bwd_e_bh": bh,
+names = {"nrm_pwattn_fwd": fwd, "nrm_pwattn_bwd_dz": pick("bwd_dz_"), "pwattn_bwd_e_bt": bt, "pwattn_bwd_e_dw": dw, "pwattn_bwd_e_bh": bh,
          "pwattn_bwd_rw_dtdh": pick("bwd_dp_rw_kernel")}
 traffic = dict(stamp)
 traffic["_note"] = ("rocprofv3 PMC (separate passes, scripts/collect_profiles.sh), mean per full-size launch. FETCH_SIZE/WRITE_SIZE are KB. "
