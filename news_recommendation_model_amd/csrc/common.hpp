@@ -82,9 +82,15 @@ __device__ __forceinline__ float wave_sum64(float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void store_b128_guarded(u32x4 v, __amdgpu_buffer_rsrc_t rs, unsigned voffset, int soffset) {
     __builtin_amdgcn_raw_buffer_store_b128(v, rs, voffset, soffset, 0);
+    // NRM_STORE_GUARD (analysis builds only; scripts/_diag/store_hazard_isa.py): 0 = no guard, 1 = the wait
+    // states alone, 2 (default) = wait states pinned behind the store by scheduling barriers
+#if !defined(NRM_STORE_GUARD) || NRM_STORE_GUARD == 2
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 3");
     __builtin_amdgcn_sched_barrier(0);
+#elif NRM_STORE_GUARD == 1
+    asm volatile("s_nop 3");
+#endif
 }
 #endif
 
