@@ -82,8 +82,8 @@ def parse():
                          "DataLoader + .to(device) does), prefetched one batch ahead on a copy stream; reported as "
                          "'pcie_inclusive', never as 'value'")
     ap.add_argument("--timeout", type=float, default=900.0,
-                    help="--gpus N > 1 without a launcher: seconds after which rank processes that are still running are "
-                         "terminated (then killed) and the parent exits with code 124, naming the ranks that hung")
+                    help="--gpus N > 1: seconds after which a rank that is still running exits with code 124 (in-process deadline; "
+                         "without an external launcher the parent also terminates, then kills, the rank processes and names the ranks that hung)")
     ap.add_argument("--cpu-batch", type=int, default=None)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -416,6 +416,20 @@ def main():
     # NRM_DIST_WORLD1=1: bring the process group up even for one rank, so that a one-GPU box exercises RCCL itself
     # (library load, communicator, the in-stream all-reduce of the flat gradient, barrier) on the code path of N > 1
     use_dist = world > 1 or os.environ.get("NRM_DIST_WORLD1") == "1"
+    if use_dist:
+        # in-process deadline for rank processes started by an EXTERNAL launcher (torch.distributed.run has none): a collective
+        # that never completes -- a peer that died, a capture that deadlocks -- must not hold the node forever.  The rank says so
+        # and leaves with 124; the launcher then takes its peers down.  (Ranks started by `python bench.py --gpus N` itself are
+        # also watched by their parent: wait_for_ranks.)
+        import threading
+
+        def _deadline():
+            print(f"bench.py: rank {rank} still running after {args.timeout:.0f} s (a collective that never completed?): exiting with 124",
+                  file=sys.stderr, flush=True)
+            os._exit(124)
+        watchdog = threading.Timer(args.timeout, _deadline)
+        watchdog.daemon = True
+        watchdog.start()
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")

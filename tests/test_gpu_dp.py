@@ -104,6 +104,19 @@ def test_bench_refuses_ranks_that_share_a_device(lib, tmp_path):
     assert any("not distinct" in o for o in outs), outs[0][-1500:]
 
 
+def test_bench_rank_leaves_with_124_when_a_peer_never_shows_up(lib, tmp_path):
+    """A rank started by an EXTERNAL launcher (as the driver does for N > 1) whose peer never joins: the in-process deadline
+    (--timeout) ends it with exit code 124 and a message instead of holding the node in a rendezvous / collective forever."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               NRM_DIST_BACKEND="gloo", NRM_SINGLE_DEVICE="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--timeout", "15",
+                         "--workload", "ref-default", "--batch", "8", "--no-cpu-baseline"],
+                        env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    assert pr.returncode == 124, (pr.returncode, pr.stderr.decode(errors="replace")[-1500:])
+    assert "still running after 15 s" in pr.stderr.decode(errors="replace")
+
+
 def _bench_line(env, *extra):
     pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
                          "--workload", "ref-default", "--batch", "16", "--no-cpu-baseline", *extra],
