@@ -345,7 +345,16 @@ class GraphedTrainStep:
                 train_step(model, optimizer, batch, None, alpha)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, pool=pool):
+        # With a process group the captured step contains the RCCL all-reduce, and ProcessGroupNCCL's watchdog THREAD keeps
+        # polling events (hipEventQuery) of earlier collectives: under the default "global" capture mode any such call from
+        # another thread while this one captures is an error that takes the process down ("operation not permitted when stream
+        # is capturing" -- seen once in five runs of the one-rank RCCL rehearsal).  Thread-local capture mode restricts only the
+        # capturing thread; the device is drained first so that no collective of the warm-up steps is still in flight.
+        mode = "global"
+        if dist.is_available() and dist.is_initialized():
+            torch.cuda.synchronize()
+            mode = "thread_local"
+        with torch.cuda.graph(self.graph, pool=pool, capture_error_mode=mode):
             self.loss, self.out = train_step(model, optimizer, batch, None, alpha)
 
     def replay(self):
