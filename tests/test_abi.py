@@ -68,3 +68,17 @@ def test_torch_library_ops_are_defined_without_a_gpu():
         ops.linear(torch.zeros(2, 4), torch.zeros(3, 4))
     with pytest.raises((RuntimeError, NotImplementedError)):
         torch.ops.nrm.weighted_pool_fwd(torch.zeros(1, 2, 3), torch.zeros(1, 3, 4))
+
+
+def test_gemm_tn_plans_of_the_c3_step_fill_one_round_of_wave_slots(lib):
+    """Host-side plan of nrm_gemm_tn (no GPU needed): for the weight-gradient shapes of a C3 step the wave tile is the one with the
+    fewest padded 16x16 tiles (2x8 / 8x2 for 402 x 1608, 5x5 for 400 x 400, 5x2 for 400 x 402 -- csrc/gemm.hip) and tiles x splits is
+    one round of wave tasks at that kernel's occupancy: never more than the slots (a second, mostly empty round), never under 90 %."""
+    cases = [  # ni, nj, R, wave tiles (of the chosen shape), waves per SIMD of that kernel
+        (402, 1608, 30720, 13 * 13, 4), (1608, 402, 30720, 13 * 13, 4), (400, 400, 51200, 5 * 5, 3), (400, 400, 30720, 5 * 5, 3),
+        (400, 402, 51200, 5 * 13, 4), (402, 400, 51200, 13 * 5, 4)]
+    for ni, nj, R, tiles, wps in cases:
+        ns = lib.nrm_gemm_tn_nsplit(ni, nj, R, 0)
+        assert ns % 4 == 0 and 0.9 * 1024 * wps <= tiles * ns <= 1024 * wps, (ni, nj, R, ns)
+    assert lib.nrm_gemm_tn_nsplit(64, 64, 3840, 0) == 30                  # small shapes: at least 128 rows per split
+    assert lib.nrm_gemm_tn_nsplit(0, 64, 128, 0) == 0
