@@ -23,6 +23,9 @@
 #ifndef NRM_DIAG_FWD
 #define NRM_DIAG_FWD 0        // bit 0: no accumulator-init loads, bit 1: no K-chunk DMA after the first, bit 2: no z store,
 #endif                        // bit 3: no GELU / fc2 dot (plain sum instead)
+#ifndef NRM_FWD_NW8
+#define NRM_FWD_NW8 0      // tuning: 13x1 compact-image forward as 8-wave workgroups (128 rows share a W chunk)
+#endif
 #ifndef NRM_PRIO
 #define NRM_PRIO 0        // tuning: s_setprio level of the K loops (0: none)
 #endif
@@ -51,14 +54,22 @@ __global__ void pack_wp_kernel(const float* __restrict__ w, int ldw, int D, int 
     }
 }
 
-template <int NT, int MT, bool SAVE_Z, int WPE = 2>
-__global__ __launch_bounds__(256, WPE) void pwattn_fwd_kernel(const FwdParams p) {
+// CT ("compact t", round 4): the 64 flattened rows (b,t,h) of a workgroup -- h fastest -- belong to at most floor(63 / H) + 2
+// candidates, yet every wave used to stage the candidate row of EACH of its 16 rows (a 1-KiB LDS-DMA piece of mostly identical
+// 64-byte segments per wave and K-chunk, 4 KB of LDS per stage).  With CT one wave stages the workgroup's DISTINCT candidate rows
+// (one piece: row r of the image = candidate bt0 + r, rows past the last one read 0) and every lane reads its row's fragment
+// from image row (m / H) - bt0 (a broadcast: <= 2 distinct addresses per 16-lane read group for H >= 16).  Three LDS-DMA
+// pieces per workgroup and chunk fewer, 35 KB instead of 43 KB of LDS at 13x1: FOUR workgroups per CU instead of three
+// (launch bounds 4 waves per SIMD: 121 VGPRs).  Used for H >= 16 (pwattn_fwd_launch); shorter histories keep the per-row image.
+template <int NT, int MT, bool SAVE_Z, int WPE = 2, bool CT = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, WPE) void pwattn_fwd_kernel(const FwdParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-descriptor types/builtins exist in the device pass only;
                                          // without the guard the host pass silently drops the kernel stub
-    constexpr int BM = 4 * MT * 16;       // data rows per workgroup
+    constexpr int BM = NW * MT * 16;      // data rows per workgroup (NW waves x MT row tiles of 16)
     constexpr int WROWS = NT * 16;
-    // one LDS buffer = [W chunk | t rows | h rows], every row 16 floats (64 B), unpadded (LDS-DMA image)
-    constexpr int BUF = (WROWS + 2 * BM) * 16;
+    // one LDS buffer = [W chunk | t rows | h rows], every row 16 floats (64 B), unpadded (LDS-DMA image); CT: [W chunk | h rows |
+    // 16 rows of distinct candidate rows]
+    constexpr int BUF = (WROWS + (CT ? BM + 16 : 2 * BM)) * 16;
     __shared__ __attribute__((aligned(16))) float smem[2 * BUF];       // double buffered
 
     const int tid = threadIdx.x;
@@ -74,6 +85,7 @@ __global__ __launch_bounds__(256, WPE) void pwattn_fwd_kernel(const FwdParams p)
     const int tile_id = XCD_REMAP ? (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3) : lin;
     const int m0 = tile_id * BM;
     const int T = p.T, H = p.H, D = p.D;
+    const int rows_here = min(BM, M - m0);
 
     // All global traffic goes through buffer descriptors: 32-bit lane offsets (no 64-bit pointers to keep
     // live or spill) and hardware bounds checking -- an offset >= num_records reads 0 / drops the store,
@@ -85,7 +97,6 @@ __global__ __launch_bounds__(256, WPE) void pwattn_fwd_kernel(const FwdParams p)
     const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.h_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v), 0, p.t_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w2), 0, D * 4, 0x00020000);
-    const int rows_here = min(BM, M - m0);
     const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(
         SAVE_Z ? p.z + (size_t)m0 * D : nullptr, 0, SAVE_Z ? rows_here * D * 4 : 0, 0x00020000);
 
@@ -102,8 +113,20 @@ __global__ __launch_bounds__(256, WPE) void pwattn_fwd_kernel(const FwdParams p)
         const unsigned b = bt / (unsigned)T;
         const unsigned hr = b * H + (mm - bt * H);
         const unsigned slot = (unsigned)((lane & 3) ^ swz4(rl));
-        voff_t[j] = m < M ? (bt * p.ldt + 4 * slot) * 4u : OOB;
+        voff_t[j] = (!CT && m < M) ? (bt * p.ldt + 4 * slot) * 4u : OOB;
         voff_h[j] = m < M ? (hr * p.ldh + 4 * slot) * 4u : OOB;
+    }
+    // CT: image row r (lane >> 2) holds candidate bt0 + r while that candidate has rows in this block (slots swizzled as in every
+    // image); a lane's fragment comes from image row tix = (its row's candidate) - bt0
+    const unsigned bt0 = (unsigned)m0 / (unsigned)H;
+    const unsigned bt_last = (unsigned)(m0 + rows_here - 1) / (unsigned)H;
+    const unsigned voff_tc = (CT && bt0 + (unsigned)(lane >> 2) <= bt_last) ? ((bt0 + (unsigned)(lane >> 2)) * p.ldt + 4u * (unsigned)((lane & 3) ^ swz4(lane >> 2))) * 4u : OOB;
+    int tfrag[MT];
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt) {
+        const int m = min(m0 + (wave * MT + jt) * 16 + r16, M - 1);
+        const int tix = m / H - (int)bt0;
+        tfrag[jt] = tix * 16 + 4 * (q ^ swz4(tix));
     }
     // --- epilogue rows of this lane
     unsigned voff_u[MT], voff_v[MT];
@@ -152,15 +175,22 @@ __global__ __launch_bounds__(256, WPE) void pwattn_fwd_kernel(const FwdParams p)
         // Columns >= D of the last chunk need no mask: the packed W_p is zero there.
         auto dma_chunk = [&](int c, float* buf) {
             const int wbase = (c * p.rows + nc * WROWS) * 64;             // bytes, uniform
-            for (int pc = wave; pc < NT; pc += 4)
+            for (int pc = wave; pc < NT; pc += NW)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(buf + pc * 256),
                                                          16, lane * 16, wbase + pc * 1024, 0, 0);
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
                 float* tdst = buf + (WROWS + (wave * MT + j) * 16) * 16;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_t, (__attribute__((address_space(3))) void*)tdst, 16, voff_t[j], c * 64, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (__attribute__((address_space(3))) void*)(tdst + BM * 16), 16, voff_h[j], c * 64, 0, 0);
+                if (CT) {                                                // [W | h rows | distinct t rows]
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (__attribute__((address_space(3))) void*)tdst, 16, voff_h[j], c * 64, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_t, (__attribute__((address_space(3))) void*)tdst, 16, voff_t[j], c * 64, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (__attribute__((address_space(3))) void*)(tdst + BM * 16), 16, voff_h[j], c * 64, 0, 0);
+                }
             }
+            // the workgroup's distinct candidate rows: one piece, staged by the wave with the fewest W pieces
+            if (CT && wave == (NT % NW == 0 ? NW - 1 : NT % NW))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_t, (__attribute__((address_space(3))) void*)(buf + (WROWS + BM) * 16), 16, voff_tc, c * 64, 0, 0);
         };
         auto compute = [&](const float* buf) {
             const float* Tl = buf + WROWS * 16;
@@ -168,7 +198,8 @@ __global__ __launch_bounds__(256, WPE) void pwattn_fwd_kernel(const FwdParams p)
 #pragma unroll
             for (int jt = 0; jt < MT; ++jt) {
                 const int ro = ((wave * MT + jt) * 16 + r16) * 16 + rslot;
-                pf[jt] = *reinterpret_cast<const f32x4*>(&Tl[ro]) * *reinterpret_cast<const f32x4*>(&Tl[BM * 16 + ro]);
+                if (CT) pf[jt] = *reinterpret_cast<const f32x4*>(&Tl[ro]) * *reinterpret_cast<const f32x4*>(&Tl[BM * 16 + tfrag[jt]]);
+                else pf[jt] = *reinterpret_cast<const f32x4*>(&Tl[ro]) * *reinterpret_cast<const f32x4*>(&Tl[BM * 16 + ro]);
             }
             // W fragments are read one tile ahead; the scheduling barrier keeps hipcc from hoisting
             // all NT reads in front of the MFMAs (that costs 4*NT registers).
@@ -260,15 +291,25 @@ FwdPlan pwattn_fwd_plan(int D) {
     return pl;
 }
 
-template <int NT, int MT, int WPE = 2>
+template <int NT, int MT, int WPE = 2, bool CT = false, int NW = 4>
 static hipError_t launch_fwd_t(const FwdParams& p, hipStream_t st) {
-    constexpr int BM = 4 * MT * 16;
+    constexpr int BM = NW * MT * 16;
     const long nblk = (p.M + BM - 1) / BM;
     if (nblk <= 0) return hipSuccess;
     if (nblk > 0x7fffffffL) return hipErrorInvalidValue;
-    if (p.z) hipLaunchKernelGGL((pwattn_fwd_kernel<NT, MT, true, WPE>), dim3((unsigned)nblk), dim3(256), 0, st, p);
-    else     hipLaunchKernelGGL((pwattn_fwd_kernel<NT, MT, false, WPE>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+    if (p.z) hipLaunchKernelGGL((pwattn_fwd_kernel<NT, MT, true, WPE, CT, NW>), dim3((unsigned)nblk), dim3(NW * 64), 0, st, p);
+    else     hipLaunchKernelGGL((pwattn_fwd_kernel<NT, MT, false, WPE, CT, NW>), dim3((unsigned)nblk), dim3(NW * 64), 0, st, p);
     return hipGetLastError();
+}
+
+// compact candidate image (template parameter CT): histories of at least 16 rows (a workgroup's 64 rows then span <= 5 candidates and a
+// 16-lane read group <= 2); NRM_FWD_CT=0 keeps the per-row image (round 3), =1 forces the compact one for any H >= 5
+static bool fwd_compact_t(int H, int block_rows = 64) {
+    const char* e = getenv("NRM_FWD_CT");                         // (read per launch: tests switch forms inside one process)
+    if (e && e[0] == '0') return false;
+    if ((block_rows - 1) / H + 2 > 16) return false;             // the image holds 16 candidate rows
+    if (e && e[0] == '1') return true;
+    return H >= 16;
 }
 
 hipError_t pwattn_fwd_launch(const FwdParams& p, const FwdPlan& pl, int mma, hipStream_t st) {
@@ -277,11 +318,17 @@ hipError_t pwattn_fwd_launch(const FwdParams& p, const FwdPlan& pl, int mma, hip
         case 4:  return launch_fwd_t<4, 4>(p, st);
         case 6:  return launch_fwd_t<6, 4>(p, st);
         case 8:  return launch_fwd_t<8, 3>(p, st);
-        case 10: return launch_fwd_t<10, 1, 3>(p, st);
-        case 12: return launch_fwd_t<12, 1, 3>(p, st);
-        case 13: return launch_fwd_t<13, 1, 3>(p, st);
+        case 10: return fwd_compact_t(p.H) ? launch_fwd_t<10, 1, 4, true>(p, st) : launch_fwd_t<10, 1, 3>(p, st);
+        case 12: return fwd_compact_t(p.H) ? launch_fwd_t<12, 1, 4, true>(p, st) : launch_fwd_t<12, 1, 3>(p, st);
+        case 13:
+            if (!fwd_compact_t(p.H, NRM_FWD_NW8 ? 128 : 64)) return launch_fwd_t<13, 1, 3>(p, st);
+#if NRM_FWD_NW8
+            return launch_fwd_t<13, 1, 4, true, 8>(p, st);            // tuning: 128-row workgroups of 8 waves, two per CU
+#else
+            return launch_fwd_t<13, 1, 4, true>(p, st);
+#endif
         case 14: return launch_fwd_t<14, 2>(p, st);
-        case 16: return launch_fwd_t<16, 1>(p, st);
+        case 16: return launch_fwd_t<16, 1>(p, st);        // (compact image + three workgroups per CU measured SLOWER at C5: 19.43 vs 18.76 ms)
         case 20: return launch_fwd_t<20, 1>(p, st);
         case 25: return launch_fwd_t<25, 1>(p, st);
     }

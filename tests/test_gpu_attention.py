@@ -83,6 +83,31 @@ def test_scores_and_grads_match_oracle(lib, B, T, H, D):
         assert rel_err(got[k], ref[k]) < GRAD_TOL, k
 
 
+# compact candidate image of the forward kernel (template parameter CT, csrc/pwattn_fwd.hip; default for H >= 16 on the 10 / 12 / 13 /
+# 16-tile plans): forced on from H = 5 and off, the scores and the saved pre-activation must be BIT-identical (same arithmetic, only
+# the LDS staging of the candidate rows differs) -- ragged row counts, blocks that span many candidates, D of every such plan
+@pytest.mark.parametrize("B,T,H,D", [(2, 30, 50, 400), (3, 7, 19, 388), (1, 64, 128, 768), (5, 3, 5, 160), (4, 9, 7, 192), (2, 11, 16, 400),
+                                     (3, 5, 130, 208), (1, 1, 5, 400), (7, 2, 21, 176), (2, 13, 63, 768)])
+def test_compact_candidate_image_is_bit_identical(lib, monkeypatch, B, T, H, D):
+    from news_recommendation_model_amd import ops
+    rng = np.random.default_rng(B * 1000 + T * 100 + H * 10 + D + 7)
+    w = {k: torch.from_numpy(v).cuda() for k, v in _weights(rng, D).items()}
+    t = torch.from_numpy(rng.standard_normal((B, T, D)).astype(np.float32)).cuda()
+    h = torch.from_numpy(rng.standard_normal((B, H, D)).astype(np.float32)).cuda()
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("NRM_FWD_CT", mode)
+        s, z = ops.pwattn_fwd(t, h, w["mlp.fc1.weight"], w["mlp.fc1.bias"], w["mlp.fc2.weight"], w["mlp.fc2.bias"], True, ops.MMA_F32)
+        s2, _ = ops.pwattn_fwd(t, h, w["mlp.fc1.weight"], w["mlp.fc1.bias"], w["mlp.fc2.weight"], w["mlp.fc2.bias"], False, ops.MMA_F32)
+        torch.cuda.synchronize()
+        out[mode] = (s.clone(), z.clone(), s2.clone())
+    assert torch.equal(out["0"][1], out["1"][1])                      # z
+    assert torch.equal(out["0"][0], out["1"][0]) and torch.equal(out["0"][2], out["1"][2])
+    p = {"a." + k: v.cpu() for k, v in w.items()}
+    ref = orc.pointwise_attention_scores(p, "a", t.cpu(), h.cpu())[..., 0]
+    assert rel_err(out["1"][0].cpu().numpy(), ref.numpy()) < FWD_TOL
+
+
 # full-row form of the dz pass (bwd_dz_rows_kernel: one workgroup owns all D columns of an impression; default only for B >= 512,
 # i.e. reached by the full-size tests alone): forced here on the small shapes it can take -- (D, H) -> 512 threads with <= 6 rows
 # per thread, else 1024 threads; shapes it cannot take (D = 768 / H = 128: 26 rows per thread) silently stay on the slab form
