@@ -67,7 +67,7 @@ def test_full_size_c3_eval_bn_model_properties(lib, monkeypatch):
     ops.check_index_errors("cuda")
     # forward: a row's logits do not depend on the rest of the launch (rounding only: the two-stream schedule may differ)
     assert torch.allclose(out[:B // 2], out_lo, rtol=1e-5, atol=1e-6) and torch.allclose(out[B // 2:], out_hi, rtol=1e-5, atol=1e-6)
-    assert abs(loss - 0.5 * (loss_lo + loss_hi)) <= 1e-6 * abs(loss)
+    assert abs(loss - 0.5 * (loss_lo + loss_hi)) <= 1e-5 * abs(loss)          # (fp32 means over 30 720 / 15 360 rows)
     # every weight gradient: mean over B*T rows -> full = (lo + hi) / 2
     gscale = max(float(v.abs().max()) for v in g.values())
     assert set(g) == set(g_lo) == set(g_hi) and len(g) == len(list(model.parameters()))
@@ -127,7 +127,7 @@ def test_full_size_c3_train_step_big_batch_paths_match_their_small_batch_forms(l
     small, sopt = fresh()
     out_s, loss_s, g_s = grads_of_first_step(small, sopt, defer=False)
     assert torch.allclose(out_b, out_s, rtol=1e-5, atol=1e-6)
-    assert abs(loss_b - loss_s) <= 1e-6 * abs(loss_s)
+    assert abs(loss_b - loss_s) <= 1e-5 * abs(loss_s)          # (logits agree to rounding: float atomics in the pooled rows' order)
     gscale = max(float(v.abs().max()) for v in g_s.values())
     for k in g_s:
         if k in ZERO_GRAD_KEYS:
