@@ -595,6 +595,10 @@ def main():
                 probe = {"steps": PROBE, "t_eager_ms": round(t_eager * 1e3, 4), "t_graph_ms": None, "rule": f"capture failed: {capture_error}"}
             if not args.graph:
                 graphs.clear()
+        elif args.eager:
+            probe["rule"] = "--eager: not probed"
+        else:
+            probe["rule"] = "eager: the all-reduce of this backend synchronises with the host and cannot be captured"
         run = graph_step if args.graph else eager_step
         for _ in range(args.warmup):
             run()
