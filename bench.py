@@ -60,13 +60,14 @@ def parse():
                          "C2-small, BASELINE config 2); bf16 = plain bf16 operands (misses the 1e-3 parity gate on raw scores)")
     ap.add_argument("--batch", type=int, default=None, help="override per-GPU batch")
     ap.add_argument("--graph", action="store_true",
-                    help="capture the step in a HIP graph and time graph replays (per-kernel event timing then "
-                         "comes from 3 extra eager steps outside the timed region)")
+                    help="capture the step in a HIP graph and time graph replays (per-kernel event timing then comes from 3 extra "
+                         "eager steps outside the timed region).  With --gpus N > 1 (RCCL) this is OPT-IN: the captured step then "
+                         "contains the in-stream all-reduce")
     ap.add_argument("--eager", action="store_true",
-                    help="never replay a graph.  Default (neither flag): both launch modes are timed over --probe-steps steps and "
-                         "reported (launch_probe); hipGraph replay when the eager step takes < 10 ms or the replay is >= 1 %% faster "
-                         "(C3: the captured step, which has no host-side gaps; C5: eager).  Same for --gpus N > 1 with RCCL: the "
-                         "captured step then contains the in-stream all-reduce")
+                    help="never replay a graph.  Default (neither flag), ONE process: both launch modes are timed over --probe-steps "
+                         "steps and reported (launch_probe); hipGraph replay when the eager step takes < 10 ms or the replay is >= 1 %% "
+                         "faster (C3: the captured step, which has no host-side gaps; C5: eager).  Default with a process group "
+                         "(--gpus N > 1): eager, not probed (launch_policy)")
     ap.add_argument("--batches", type=int, default=4,
                     help="resident synthetic batches per rank the steps cycle through (all in HBM before the timed region starts)")
     ap.add_argument("--probe-steps", type=int, default=10, help="steps per launch mode in the eager-vs-hipGraph probe (>= 10)")
@@ -82,8 +83,9 @@ def parse():
                          "DataLoader + .to(device) does), prefetched one batch ahead on a copy stream; reported as "
                          "'pcie_inclusive', never as 'value'")
     ap.add_argument("--timeout", type=float, default=900.0,
-                    help="--gpus N > 1: seconds after which a rank that is still running exits with code 124 (in-process deadline; "
-                         "without an external launcher the parent also terminates, then kills, the rank processes and names the ranks that hung)")
+                    help="--gpus N > 1: seconds WITHOUT PROGRESS (no step finished, no phase change: Heartbeat) after which a rank "
+                         "exits with code 124 and names the phase it hung in; without an external launcher the parent applies the "
+                         "same figure to the whole run, terminates, then kills, the rank processes and names the ranks that hung")
     ap.add_argument("--cpu-batch", type=int, default=None)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -206,6 +208,117 @@ def collective_stats(opt, world, fallback_events=None):
     ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     bus = (2.0 * (world - 1) / world * opt.nbytes / (ms * 1e-3) / 1e9) if world > 1 and ms > 0 else 0.0
     return {"allreduce_ms": round(ms, 4), "bus_GBps": round(bus, 2), "allreduce_events": len(ev), "allreduce_timed_in": src}
+
+
+class Heartbeat:
+    """In-process hang detector of a rank (torch.distributed.run has none).  ``beat(phase)`` is called after the rendezvous, at
+    every phase change and after every step; a daemon thread ends the process with exit code 124 when NO beat arrived for
+    ``timeout`` seconds, naming the phase it was in -- a collective that never completes, a peer that died, a capture that
+    deadlocks.  A healthy long run (large --steps, C5 on N GPUs) is never killed: the deadline is per beat, not per run
+    (it used to be one threading.Timer(timeout) over the whole run).  ``stop()`` before the final print."""
+
+    def __init__(self, timeout, rank=0, poll=None, out=None, _exit=os._exit):
+        import threading
+        self.timeout, self.rank, self.out, self._exit = float(timeout), rank, out, _exit
+        self.phase, self.last, self.beats = "start", time.monotonic(), 0
+        self._stop = threading.Event()
+        self._poll = poll if poll is not None else min(5.0, max(0.05, self.timeout / 4))
+        self._thread = threading.Thread(target=self._run, name="bench-heartbeat", daemon=True)
+        self._thread.start()
+
+    def beat(self, phase=None):
+        if phase is not None:
+            self.phase = phase
+        self.last = time.monotonic()
+        self.beats += 1
+
+    def stop(self):
+        self._stop.set()
+
+    def _run(self):
+        while not self._stop.wait(self._poll):
+            idle = time.monotonic() - self.last
+            if idle > self.timeout:
+                print(f"bench.py: rank {self.rank} still running after {self.timeout:.0f} s without progress in phase "
+                      f"'{self.phase}' ({self.beats} heartbeats so far; a collective that never completed?): exiting with 124",
+                      file=self.out or sys.stderr, flush=True)
+                self._exit(124)
+                return
+
+
+def launch_policy(graph, eager, use_dist, backend):
+    """Launch mode of the timed region -> ("graph" | "eager" | "probe", rule).
+
+    One process, no process group: both modes are timed over --probe-steps steps and the faster one runs ("probe").
+    With a process group (N > 1, or the one-rank RCCL rehearsal) the DEFAULT IS EAGER: a captured step
+    contains the in-stream RCCL all-reduce, ProcessGroupNCCL's watchdog thread polls events while the main thread captures, and
+    an abort on that thread never reaches an `except` here -- the first multi-device contact of this code is the driver's
+    scaling run, where an abort means no number, and what capture buys is <= 2 % of a C3 step.  ``--graph`` opts in (thread-local
+    capture mode, trainer.GraphedTrainStep); gloo synchronises with the host inside its collective and cannot be captured."""
+    if graph and eager:
+        raise SystemExit("bench.py: --graph and --eager exclude each other")
+    if use_dist and backend != "nccl":
+        if graph:
+            raise SystemExit("bench.py --graph: a gloo all-reduce cannot be captured into a HIP graph (use the nccl backend)")
+        return "eager", "eager: the all-reduce of this backend synchronises with the host and cannot be captured"
+    if graph:
+        return "graph", "--graph: forced" + (" (the captured step contains the in-stream RCCL all-reduce)" if use_dist else "")
+    if eager:
+        return "eager", "--eager: not probed"
+    if use_dist:
+        return "eager", ("eager by default with a process group: the captured step with the RCCL all-reduce inside is opt-in "
+                         "(--graph); not probed")
+    return "probe", "hipGraph replay if the eager step takes < 10 ms or if the replay is >= 1 % faster"
+
+
+def gather_device_identities(ident, world):
+    """Every rank contributes its device identity; -> (list by rank, all distinct?)."""
+    devices = [None] * world
+    dist.all_gather_object(devices, ident)
+    return devices, len({(d["uuid"], d["pci"]) for d in devices}) == world
+
+
+def gather_rank_times(elapsed, steps, world, dev):
+    """-> (every rank's own ms per step, the slowest rank's elapsed seconds = the job's time)."""
+    mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    per_rank_ms = [float(x.item()) / steps * 1e3 for x in allr]
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return per_rank_ms, float(tt.item())
+
+
+def replicas_hold_identical_weights(flat_param):
+    """Same init + averaged gradients: two checksums of the flat parameter buffer must be equal on every rank."""
+    chk = torch.stack([flat_param.double().sum(), flat_param.double().abs().sum()])
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool(torch.equal(lo, hi))
+
+
+def collective_object(opt, world, devices, table_events=None):
+    """The `collective` object of the JSON line (what a scaling run is checked against: DESIGN.md section 6)."""
+    return dict({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "all_reduce_per_step": 1,
+                 "launcher": "self (child processes)" if os.environ.get("NRM_BENCH_CHILD") else "external",
+                 "devices": devices, "devices_distinct": len({(d["uuid"], d["pci"]) for d in devices}) == world},
+                **collective_stats(opt, world, table_events))
+
+
+def per_rank_object(per_rank_ms):
+    return {"min": round(min(per_rank_ms), 3), "max": round(max(per_rank_ms), 3), "ranks": [round(x, 3) for x in per_rank_ms]}
+
+
+def job_fields(world, per_gpu_batch, steps, elapsed, per_rank_ms, opt, use_dist, devices, replicas_in_sync, table_events=None):
+    """The fields of the JSON line that describe the JOB (all N ranks): whole-job throughput over the slowest rank's time, the
+    rank count as the process group saw it, every rank's own step time, the one collective of a step.  A scaling record is
+    checked against these (n_gpus == collective.world_size == N, devices_distinct, per-rank times, all-reduce time and bus
+    bandwidth); tests/test_dp_gloo.py runs this function under a two-rank gloo group."""
+    return {"value": round(world * per_gpu_batch * steps / elapsed, 2), "n_gpus": world, "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "per_rank_ms_per_step": per_rank_object(per_rank_ms), "grad_allreduce_bytes": opt.nbytes if use_dist else 0,
+            "replicas_in_sync": replicas_in_sync,
+            "collective": collective_object(opt, world, devices, table_events) if use_dist else None}
 
 
 HEAVY = ("nrm_pwattn_fwd", "pwattn_bwd_e_bt", "pwattn_bwd_e_dw", "pwattn_bwd_e_bh", "pwattn_bwd_rw_dtdh", "nrm_pwattn_bwd_dz")   # event-timed inside the timed region
@@ -416,20 +529,15 @@ def main():
     # NRM_DIST_WORLD1=1: bring the process group up even for one rank, so that a one-GPU box exercises RCCL itself
     # (library load, communicator, the in-stream all-reduce of the flat gradient, barrier) on the code path of N > 1
     use_dist = world > 1 or os.environ.get("NRM_DIST_WORLD1") == "1"
-    if use_dist:
-        # in-process deadline for rank processes started by an EXTERNAL launcher (torch.distributed.run has none): a collective
-        # that never completes -- a peer that died, a capture that deadlocks -- must not hold the node forever.  The rank says so
-        # and leaves with 124; the launcher then takes its peers down.  (Ranks started by `python bench.py --gpus N` itself are
-        # also watched by their parent: wait_for_ranks.)
-        import threading
+    # in-process hang detector for rank processes started by an EXTERNAL launcher (torch.distributed.run has none): a collective
+    # that never completes must not hold the node forever.  The rank names the phase it hung in and leaves with 124; the
+    # launcher then takes its peers down.  (Ranks started by `python bench.py --gpus N` itself are also watched by their parent.)
+    hb = Heartbeat(args.timeout, rank) if use_dist else None
 
-        def _deadline():
-            print(f"bench.py: rank {rank} still running after {args.timeout:.0f} s (a collective that never completed?): exiting with 124",
-                  file=sys.stderr, flush=True)
-            os._exit(124)
-        watchdog = threading.Timer(args.timeout, _deadline)
-        watchdog.daemon = True
-        watchdog.start()
+    def beat(phase=None):
+        if hb is not None:
+            hb.beat(phase)
+    beat("rendezvous")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -445,9 +553,8 @@ def main():
         ident = {"rank": rank, "current_device": torch.cuda.current_device(), "name": pr_.name,
                  "uuid": str(getattr(pr_, "uuid", "")), "pci": f"{getattr(pr_, 'pci_domain_id', 0):04x}:{getattr(pr_, 'pci_bus_id', -1):02x}:"
                                                               f"{getattr(pr_, 'pci_device_id', -1):02x}"}
-        devices = [None] * world
-        dist.all_gather_object(devices, ident)
-        distinct = len({(d["uuid"], d["pci"]) for d in devices}) == world
+        beat("device identities")
+        devices, distinct = gather_device_identities(ident, world)
         if not distinct and os.environ.get("NRM_SINGLE_DEVICE") != "1":
             raise SystemExit(f"bench.py: {world} ranks but their devices are not distinct: {devices} "
                              "(one process per GPU; NRM_SINGLE_DEVICE=1 only for the one-GPU rehearsal)")
@@ -489,6 +596,7 @@ def main():
     def eager_step():
         tb_ = tbs[counter["i"] % NB]
         counter["i"] += 1
+        beat()
         return trainer.train_step(model, opt, tb_, reducer)
 
     graphs = []
@@ -504,6 +612,7 @@ def main():
     def graph_step():
         g = graphs[counter["i"] % NB]
         counter["i"] += 1
+        beat()
         return g.replay()
 
     def time_steps(fn, n):
@@ -520,6 +629,7 @@ def main():
         return t_
 
     # the very first step of the process (initial weights, batch 0): the loss the oracle reproduces (cpu_baseline leg)
+    beat("first step")
     l0, _ = eager_step()
     first_step_loss = float(l0)
 
@@ -537,6 +647,7 @@ def main():
         # per-kernel durations cannot be event-timed inside a graph, and a kernel that shares the chip with a kernel of another
         # stream cannot be priced against a roofline: take them from 3 eager ONE-STREAM steps first (no second attention stream,
         # no weight-gradient stream); the first of them also runs under the matrix-FLOP meter (roofline.step)
+        beat("kernel table steps")
         inv.two_streams = False
         prev_wg = os.environ.get("NRM_WGRAD_STREAM")
         os.environ["NRM_WGRAD_STREAM"] = "0"
@@ -560,18 +671,17 @@ def main():
             del os.environ["NRM_WGRAD_STREAM"]
         else:
             os.environ["NRM_WGRAD_STREAM"] = prev_wg
-        # Launch mode of the timed region.  --graph / --eager force it.  Otherwise BOTH are timed over PROBE >= 10 steps in the
-        # same state of the box (two 2-step probes with a 0.3 % threshold were inside run-to-run noise), both times are
-        # reported, and the captured step is taken when a step is launch-bound (< 10 ms) or when it is at least 1 % faster.  With
-        # a process group (N > 1, or the one-rank RCCL rehearsal) the captured step CONTAINS the in-stream all-reduce; gloo (the
-        # one-GPU two-rank rehearsal) synchronises with the host inside its collective and cannot be captured.
-        can_capture = not use_dist or backend == "nccl"
+        # Launch mode of the timed region (launch_policy): --graph / --eager force it; one process without a process group times
+        # BOTH over PROBE >= 10 steps in the same state of the box and takes the captured step when a step is launch-bound
+        # (< 10 ms) or the replay is at least 1 % faster; with a process group the step is eager unless --graph asks otherwise.
+        mode, rule = launch_policy(args.graph, args.eager, use_dist, backend)
+        probe["rule"] = rule
         capture_error = None
-        if args.graph and not can_capture:
-            raise SystemExit("bench.py --graph: a gloo all-reduce cannot be captured into a HIP graph (use the nccl backend)")
-        if not args.eager and can_capture:
+        if mode in ("graph", "probe"):
             PROBE = max(10, args.probe_steps)
+            beat("launch probe: eager steps")
             t_eager = time_steps(eager_step, PROBE)
+            beat("graph capture")
             try:
                 capture_graphs()
                 ok = 1.0
@@ -583,10 +693,10 @@ def main():
                 dist.all_reduce(tt_, op=dist.ReduceOp.MIN)
                 ok = float(tt_.item())
             if ok:
+                beat("launch probe: graph replays")
                 t_graph = time_steps(graph_step, PROBE)
-                probe = {"steps": PROBE, "t_eager_ms": round(t_eager * 1e3, 4), "t_graph_ms": round(t_graph * 1e3, 4),
-                         "rule": "hipGraph replay if forced, if the eager step takes < 10 ms, or if the replay is >= 1 % faster"}
-                if not args.graph:
+                probe = {"steps": PROBE, "t_eager_ms": round(t_eager * 1e3, 4), "t_graph_ms": round(t_graph * 1e3, 4), "rule": rule}
+                if mode == "probe":
                     args.graph = t_eager < 10e-3 or t_graph < 0.99 * t_eager
             else:
                 graphs.clear()
@@ -595,10 +705,7 @@ def main():
                 probe = {"steps": PROBE, "t_eager_ms": round(t_eager * 1e3, 4), "t_graph_ms": None, "rule": f"capture failed: {capture_error}"}
             if not args.graph:
                 graphs.clear()
-        elif args.eager:
-            probe["rule"] = "--eager: not probed"
-        else:
-            probe["rule"] = "eager: the all-reduce of this backend synchronises with the host and cannot be captured"
+        beat("warm-up + timed steps")
         run = graph_step if args.graph else eager_step
         for _ in range(args.warmup):
             run()
@@ -612,6 +719,7 @@ def main():
     else:
         # --timed-kernel-events (round-1/2 behaviour): the full per-kernel table comes from 3 extra eager steps outside the timed
         # region; inside it only the four big attention kernels (8 launches per step) are bracketed by events
+        beat("warm-up + timed steps (kernel events inside)")
         inv.two_streams = False
         table_collective_events = None
         for _ in range(args.warmup):
@@ -642,20 +750,11 @@ def main():
         events = events + [e for e in table_events if e[0] not in HEAVY]
     per_rank_ms = [elapsed / args.steps * 1e3]
     if use_dist:
+        beat("gathering rank times")
         # every rank's own time for the K steps (stragglers show here); the job's time is the slowest rank's
-        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in allr]
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        per_rank_ms, elapsed = gather_rank_times(elapsed, args.steps, world, dev)
         # replicas must still hold identical weights after the timed steps (same init, averaged gradients)
-        chk = torch.stack([opt.flat_param.double().sum(), opt.flat_param.double().abs().sum()])
-        lo, hi = chk.clone(), chk.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        replicas_in_sync = bool(torch.equal(lo, hi))
+        replicas_in_sync = replicas_hold_identical_weights(opt.flat_param)
     else:
         replicas_in_sync = True
 
@@ -742,6 +841,7 @@ def main():
         except Exception as e:
             traffic_note = "unreadable profile: " + repr(e)
 
+    beat("assembling the line")
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         # whole-step roofline: the matrix FLOPs one step ISSUES on the MFMA pipe (attention contractions + every dense GEMM incl.
@@ -756,10 +856,11 @@ def main():
                          "achieved": round(mf / (ms * 1e-3) / 1e12, 2), "frac": round(mf / (ms * 1e-3) / 1e12 / peak, 4),
                          "ms_at_peak": round(mf / (peak * 1e12) * 1e3, 3)}
         roof["step"] = step_roof
+        job = job_fields(world, B, args.steps, elapsed, per_rank_ms, opt, use_dist, devices, replicas_in_sync, table_collective_events)
         line = {
-            "metric": "train impressions/sec", "value": round(world * B * args.steps / elapsed, 2),
-            "unit": "impressions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "train impressions/sec", "value": job["value"],
+            "unit": "impressions/s", "n_gpus": job["n_gpus"], "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": job["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16": "bf16 (attention contractions and dense GEMMs: bf16 MFMA operands, fp32 accumulate; rest f32)",
                       "bf16x3": "bf16x3 (attention contractions and dense GEMMs: bf16 MFMA on hi/lo split operands, fp32 accumulate; rest f32)"}[args.dtype],
             "data": "synthetic",
@@ -772,16 +873,11 @@ def main():
             "loss": round(float(loss), 6), "first_step_loss": round(first_step_loss, 6),
             "loss_note": f"first_step_loss: initial weights, batch 0 (the oracle's value for its sample of the same batch: cpu_baseline."
                          f"hip_vs_oracle_first_step.oracle_loss); loss: last timed step, after {counter['i']} steps cycling {NB} resident batches",
-            "launch_probe": probe, "per_rank_ms_per_step": {"min": round(min(per_rank_ms), 3), "max": round(max(per_rank_ms), 3),
-                                                            "ranks": [round(x, 3) for x in per_rank_ms]},
+            "launch_probe": probe, "per_rank_ms_per_step": job["per_rank_ms_per_step"],
             "roofline": dict(roof, traffic=traffic, traffic_source=traffic_note),
             "kernels": {k: {"launches": v["launches"], "mean_ms": round(v["mean_ms"], 4)} for k, v in kern.items()},
-            "grad_allreduce_bytes": opt.nbytes if use_dist else 0, "replicas_in_sync": replicas_in_sync,
-            "collective": (dict({"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                                 "all_reduce_per_step": 1, "launcher": "self (child processes)" if os.environ.get("NRM_BENCH_CHILD") else "external",
-                                 "devices": devices, "devices_distinct": len({(d["uuid"], d["pci"]) for d in devices}) == world},
-                                **collective_stats(opt, world, table_collective_events))
-                           if use_dist else None),
+            "grad_allreduce_bytes": job["grad_allreduce_bytes"], "replicas_in_sync": job["replicas_in_sync"],
+            "collective": job["collective"],
         }
         if pcie is not None:
             line["pcie_inclusive"] = pcie
@@ -789,9 +885,12 @@ def main():
                                                                   "ref-default": "refdefault"}.get(args.workload, "c3_large"))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(dims, wl, args.cpu_seconds, args.cpu_batch, args.dtype)
+        beat("printing")
         print(json.dumps(line), flush=True)
     if use_dist:
+        beat("final barrier")
         dist.barrier()                 # rank 0 is still printing / probing parity: leave together
+        hb.stop()
         dist.destroy_process_group()
 
 

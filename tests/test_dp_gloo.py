@@ -169,3 +169,124 @@ def test_launcher_deadline_terminates_hung_ranks():
     log = io.StringIO()
     assert bench.wait_for_ranks(procs, timeout=30.0, out=log) == 3
     assert procs[1].poll() is not None and "rank 0 exited with code 3" in log.getvalue()
+
+
+def _import_bench():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    try:
+        import bench
+    finally:
+        sys.path.pop(0)
+    return bench
+
+
+def test_multi_rank_runs_step_eagerly_unless_graph_is_asked_for():
+    """with a process group the DEFAULT launch mode is eager (an abort on ProcessGroupNCCL's watchdog thread
+    during a capture never reaches an `except`, and the first multi-device contact of this code is the driver's scaling run);
+    the captured step with the RCCL all-reduce inside is opt-in.  One process without a group still probes both modes."""
+    bench = _import_bench()
+    mode, rule = bench.launch_policy(graph=False, eager=False, use_dist=True, backend="nccl")
+    assert mode == "eager" and "opt-in" in rule and "--graph" in rule
+    assert bench.launch_policy(True, False, True, "nccl")[0] == "graph"
+    assert bench.launch_policy(False, True, True, "nccl")[0] == "eager"
+    assert bench.launch_policy(False, False, True, "gloo")[0] == "eager"
+    assert bench.launch_policy(False, False, False, "nccl")[0] == "probe"
+    assert bench.launch_policy(True, False, False, "nccl")[0] == "graph"
+    assert bench.launch_policy(False, True, False, "nccl")[0] == "eager"
+    with pytest.raises(SystemExit):
+        bench.launch_policy(True, False, True, "gloo")         # gloo cannot be captured: refused, not silently eager
+    with pytest.raises(SystemExit):
+        bench.launch_policy(True, True, False, "nccl")
+
+
+def test_heartbeat_fires_on_no_progress_only_and_names_the_phase():
+    """the in-process deadline is a hang detector, not a whole-run limit.  A rank that keeps finishing steps is never
+    ended however long it runs; one that stops making progress leaves with 124 and says in which phase."""
+    import io
+    import time
+    bench = _import_bench()
+    codes, log = [], io.StringIO()
+    hb = bench.Heartbeat(0.4, rank=3, poll=0.05, out=log, _exit=codes.append)
+    t0 = time.monotonic()
+    while time.monotonic() - t0 < 1.2:                  # three deadlines' worth of healthy progress
+        hb.beat("timed steps")
+        time.sleep(0.05)
+    assert codes == [] and hb.beats > 10
+    hb.beat("final barrier")
+    time.sleep(0.9)                                      # ... and now a hang
+    assert codes == [124]
+    text = log.getvalue()
+    assert "rank 3" in text and "'final barrier'" in text and "without progress" in text
+    # a stopped heartbeat never fires (the final print of rank 0 may take long: fwd_auc_parity, cpu_baseline)
+    codes2 = []
+    hb2 = bench.Heartbeat(0.2, poll=0.05, out=io.StringIO(), _exit=codes2.append)
+    hb2.stop()
+    time.sleep(0.6)
+    assert codes2 == []
+
+
+def _line_worker(rank, world, port, out):
+    """One rank of a `bench.py --gpus 2` run as far as a box without a GPU can take it: the process-group half of main() -- device
+    identities, launch policy, per-rank times, replica check, the job's fields of the JSON line -- on CPU tensors over gloo."""
+    import types
+    bench = _import_bench()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cpu")
+        ident = {"rank": rank, "current_device": rank, "name": "AMD Instinct MI355X", "uuid": f"GPU-{rank:04d}", "pci": f"0000:{rank + 5:02x}:00"}
+        devices, distinct = bench.gather_device_identities(ident, world)
+        assert distinct and [d["rank"] for d in devices] == list(range(world))
+        same, not_distinct = bench.gather_device_identities(dict(ident, uuid="GPU-0000", pci="0000:05:00"), world)
+        assert not not_distinct                                               # two ranks on one device are seen
+        mode, rule = bench.launch_policy(False, False, True, "nccl")          # what the 8-GPU run decides
+        assert mode == "eager"
+        opt = types.SimpleNamespace(nbytes=21_170_420, collective_events=None, flat_param=torch.arange(16, dtype=torch.float32))
+        elapsed = 0.632 + 0.010 * rank                                       # rank 1 is the straggler
+        per_rank_ms, job_elapsed = bench.gather_rank_times(elapsed, 20, world, dev)
+        assert len(per_rank_ms) == world and abs(job_elapsed - 0.642) < 1e-12
+        in_sync = bench.replicas_hold_identical_weights(opt.flat_param)
+        assert in_sync
+        drift = opt.flat_param + (1e-3 if rank == 1 else 0.0)
+        assert not bench.replicas_hold_identical_weights(drift)             # a replica that drifted is seen
+        job = bench.job_fields(world, 1024, 20, job_elapsed, per_rank_ms, opt, True, devices, in_sync, None)
+        out.put((rank, json_safe(job)))
+    except Exception as e:                              # pragma: no cover
+        out.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def json_safe(obj):
+    import json
+    return json.loads(json.dumps(obj))
+
+
+def test_two_rank_bench_line_job_fields_gloo():
+    """The JSON line of a multi-rank run carries n_gpus == collective.world_size == N, devices_distinct, every rank's own
+    ms_per_step, the collective's statistics keys, and the whole-job value over the SLOWEST rank's time."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_line_worker, args=(r, 2, port, out)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(180)
+    res = dict(out.get(timeout=5) for _ in range(2))
+    assert all(isinstance(v, dict) for v in res.values()), res
+    for job in res.values():                                               # every rank assembles the same job description
+        assert job["n_gpus"] == 2 and job["collective"]["world_size"] == 2 and job["collective"]["backend"] == "gloo"
+        assert job["collective"]["devices_distinct"] is True and len(job["collective"]["devices"]) == 2
+        assert job["collective"]["all_reduce_per_step"] == 1
+        assert {"allreduce_ms", "bus_GBps"} <= set(job["collective"])       # collective_stats (None here: no GPU events)
+        pr_ = job["per_rank_ms_per_step"]
+        assert pr_["ranks"] == [31.6, 32.1] and pr_["min"] == 31.6 and pr_["max"] == 32.1
+        assert job["ms_per_step"] == 32.1                                   # the slowest rank's time is the job's
+        assert abs(job["value"] - 2 * 1024 * 20 / 0.642) < 0.01
+        assert job["grad_allreduce_bytes"] == 21_170_420 and job["replicas_in_sync"] is True
+    assert res[0] == res[1]
+    assert all(pr.exitcode == 0 for pr in procs)

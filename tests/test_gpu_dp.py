@@ -131,8 +131,8 @@ def test_bench_one_rank_through_rccl(lib, tmp_path):
     """RCCL itself under the data-parallel step, as far as a one-GPU box can take it: a process group of ONE rank with
     backend nccl (NRM_DIST_WORLD1=1), so the communicator, the in-stream all-reduce of the flat gradient (ReduceOp.AVG),
     the barrier-bracketed timing and the replica check of bench.py all run through librccl on the code path of N > 1 --
-    eagerly, as a CAPTURED step with the all-reduce inside the HIP graph (what `--gpus N` now probes and
-    may choose), and through the default launch-mode probe."""
+    eagerly (forced, and as the default of any run with a process group) and as a CAPTURED step with the all-reduce inside
+    the HIP graph (`--graph`, opt-in since round 5)."""
     env = dict(os.environ, NRM_DIST_WORLD1="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "NRM_DIST_BACKEND", "NRM_SINGLE_DEVICE"):
@@ -148,12 +148,12 @@ def test_bench_one_rank_through_rccl(lib, tmp_path):
     assert graphed["config"]["launch"] == "hipGraph replay" and graphed["collective"]["backend"] == "nccl"
     assert graphed["replicas_in_sync"] is True and graphed["first_step_loss"] == line["first_step_loss"]
     assert graphed["collective"]["allreduce_timed_in"].startswith("3 eager") and graphed["collective"]["allreduce_ms"] > 0
-    # the default: both modes probed over >= 10 steps each and reported; this launch-bound shape takes the captured step
+    # the default WITH a process group: eager, not probed -- the captured step with RCCL inside is opt-in
     env["MASTER_PORT"] = str(_free_port())
-    probed = _bench_line(env)
-    pb = probed["launch_probe"]
-    assert pb["steps"] >= 10 and pb["t_eager_ms"] > 0 and pb["t_graph_ms"] > 0
-    assert probed["config"]["launch"] == "hipGraph replay" and probed["replicas_in_sync"] is True
+    dflt = _bench_line(env)
+    assert dflt["config"]["launch"] == "eager" and dflt["launch_probe"]["steps"] == 0
+    assert "opt-in" in dflt["launch_probe"]["rule"] and dflt["replicas_in_sync"] is True
+    assert dflt["collective"]["allreduce_timed_in"] == "timed region" and dflt["collective"]["allreduce_events"] == 3
     # the one-rank average must leave the step itself unchanged: same losses as the run without a process group
     env.pop("NRM_DIST_WORLD1")
     line2 = _bench_line(env, "--eager")
