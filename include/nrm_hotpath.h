@@ -207,7 +207,8 @@ int nrm_small_linear_relu_bwd(const void* x, int x_is_f64, const float* weight, 
 
 /* ---- loss (reference models/user_model.py:37-43): (1-alpha)*BCE(softmax_T(out), y) + alpha*BCE(softmax_T(out +
  * delta[id]), y), mean over B*T, log clamped at -100.  Writes loss_sum[0] += loss, dout [B,T] = dL/dout and
- * ddelta[id[b]] += dL/ddelta (loss_sum and ddelta must be zero-initialised).  T <= 256.  delta has n_delta entries;
+ * ddelta[id[b]] += dL/ddelta (loss_sum and ddelta must be zero-initialised).  Any T >= 1 (a lane
+ * keeps its candidates in registers up to T = 256 and re-reads the row beyond).  delta has n_delta entries;
  * a negative id counts from the end as in torch indexing, an id still outside [0, n_delta) is clamped and sets
  * err[0] = 1 (the reference raises IndexError at user_model.py:40; never an out-of-bounds access here).
  * out_stride / dout_stride: floats between consecutive (b, t) entries -- 1 for dense [B,T]; 4 for the single column of a

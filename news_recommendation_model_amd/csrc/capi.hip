@@ -441,7 +441,8 @@ int nrm_loss_fwd_bwd(const float* out, int out_stride, const void* label, int la
                      long n_delta, float alpha, int B, int T, float* loss_sum, float* dout, int dout_stride, float* ddelta, int* err,
                      nrm_stream_t stream) {
     if (!out || !label || !user_id || !delta || !loss_sum || !dout || !ddelta || !err) return fail(NRM_EINVAL, "nrm_loss_fwd_bwd: null pointer");
-    if (B < 0 || T <= 0 || T > 256 || n_delta < 1) return fail(NRM_EINVAL, "nrm_loss_fwd_bwd: B=%d T=%d n_delta=%ld (T <= 256, n_delta >= 1)", B, T, n_delta);
+    if (B < 0 || T <= 0 || n_delta < 1 || (long)B * T >= (1L << 29))
+        return fail(NRM_EINVAL, "nrm_loss_fwd_bwd: B=%d T=%d n_delta=%ld (T >= 1, n_delta >= 1, B*T < 2^29)", B, T, n_delta);
     if (out_stride < 1 || dout_stride < 1 || (dout_stride == 4 && !al16(dout)))
         return fail(NRM_EINVAL, "nrm_loss_fwd_bwd: out_stride=%d dout_stride=%d (>= 1; dout 16-byte aligned for stride 4)", out_stride, dout_stride);
     return check_hip(nrm::loss_launch(out, out_stride, label, label_is_f64, user_id, delta, n_delta, alpha, B, T, loss_sum, dout, dout_stride,

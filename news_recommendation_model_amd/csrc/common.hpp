@@ -79,8 +79,8 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // SGPR soffset it inserts nothing, yet on gfx950 the store was seen delivering values the next VALU instructions had already
 // written into its data registers (pwattn_fwd_walk_kernel: gelu(z) instead of z in 0.1 % of the stored pre-activations).  The
 // wait states are pinned right behind the store.
-#if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void store_b128_guarded(u32x4 v, __amdgpu_buffer_rsrc_t rs, unsigned voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass only parses the kernels that call this)
     __builtin_amdgcn_raw_buffer_store_b128(v, rs, voffset, soffset, 0);
     // NRM_STORE_GUARD (analysis builds only; scripts/_diag/store_hazard_isa.py): 0 = no guard, 1 = the wait
     // states alone, 2 (default) = wait states pinned behind the store by scheduling barriers
@@ -91,8 +91,8 @@ __device__ __forceinline__ void store_b128_guarded(u32x4 v, __amdgpu_buffer_rsrc
 #elif NRM_STORE_GUARD == 1
     asm volatile("s_nop 3");
 #endif
-}
 #endif
+}
 
 __host__ __device__ inline int swz4(int row) { return ((row >> 3) & 1) * 3; }
 

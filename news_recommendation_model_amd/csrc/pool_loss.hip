@@ -256,10 +256,82 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out
     }
 }
 
+// More than 256 candidates per impression (the reference takes any T: models/user_model.py:37-43 is shape-agnostic): the same
+// arithmetic with the row re-read from memory in every pass instead of held in four registers per lane -- a lane still owns
+// t = lane, lane + 64, ... and sums them in that order, so for T <= 256 both kernels produce bit-identical results.
+template <typename LT>
+__global__ __launch_bounds__(256) void loss_long_kernel(const float* __restrict__ out, int so, const LT* __restrict__ label,
+                                                        const long* __restrict__ uid, const float* __restrict__ delta,
+                                                        long n_delta, float alpha, int B, int T, float* __restrict__ loss_sum,
+                                                        float* __restrict__ dout, int sd, float* __restrict__ ddelta, int* __restrict__ err) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    long id = uid[b];
+    if (id < 0) id += n_delta;
+    if (id < 0 || id >= n_delta) {
+        if (lane == 0) *err = 1;
+        id = id < 0 ? 0 : n_delta - 1;
+    }
+    const float dl = delta[id];
+    const float inv = 1.0f / ((float)B * (float)T);
+    const float* ob = out + (long)b * T * so;
+    const LT* yb = label + (long)b * T;
+    float* gb = dout + (long)b * T * sd;
+    float mx = -3.0e38f;
+    for (int t = lane; t < T; t += 64) mx = fmaxf(mx, ob[(long)t * so]);
+    mx = wave_max64(mx);
+    float total = 0.f, gsum_shift = 0.f;
+    for (int term = 0; term < 2; ++term) {
+        const float shift = term ? dl : 0.f;
+        const float wt = term ? alpha : 1.0f - alpha;
+        float se = 0.f;
+        for (int t = lane; t < T; t += 64) se += __expf((ob[(long)t * so] + shift) - (mx + shift));
+        se = wave_sum64(se);
+        const float rse = 1.0f / se;
+        float pdp = 0.f, lsum = 0.f;
+        for (int t = lane; t < T; t += 64) {
+            const float p = __expf((ob[(long)t * so] + shift) - (mx + shift)) * rse;
+            const float y = (float)yb[t];
+            const float lp = fmaxf(__logf(p), -100.f), l1p = fmaxf(__logf(1.0f - p), -100.f);
+            lsum += -(y * lp + (1.0f - y) * l1p);
+            pdp += p * ((p - y) / fmaxf(p * (1.0f - p), 1e-12f));
+        }
+        pdp = wave_sum64(pdp);
+        lsum = wave_sum64(lsum);
+        total += wt * lsum;
+        float gs = 0.f;
+        for (int t = lane; t < T; t += 64) {
+            const float p = __expf((ob[(long)t * so] + shift) - (mx + shift)) * rse;
+            const float y = (float)yb[t];
+            const float dp = (p - y) / fmaxf(p * (1.0f - p), 1e-12f);
+            const float gg = wt * inv * p * (dp - pdp);
+            gs += gg;
+            // this lane wrote element t in term 0 and is the only one to touch it: plain read-modify-write in term 1
+            if (sd == 4) *reinterpret_cast<f32x4*>(gb + (long)t * 4) = f32x4{term ? gb[(long)t * 4] + gg : gg, 0.f, 0.f, 0.f};
+            else gb[(long)t * sd] = term ? gb[(long)t * sd] + gg : gg;
+        }
+        if (term) gsum_shift = wave_sum64(gs);
+    }
+    if (lane == 0) {
+        atomicAdd(loss_sum, total * inv);
+        atomicAdd(ddelta + id, gsum_shift);
+    }
+}
+
 hipError_t loss_launch(const float* out, int out_stride, const void* label, int label_is_f64, const long* uid, const float* delta,
                        long n_delta, float alpha, int B, int T, float* loss_sum, float* dout, int dout_stride, float* ddelta, int* err,
                        hipStream_t st) {
     if (B <= 0) return hipSuccess;
+    if (T > 256) {
+        if (label_is_f64)
+            hipLaunchKernelGGL(loss_long_kernel<double>, dim3((B + 3) / 4), dim3(256), 0, st, out, out_stride, (const double*)label, uid,
+                               delta, n_delta, alpha, B, T, loss_sum, dout, dout_stride, ddelta, err);
+        else
+            hipLaunchKernelGGL(loss_long_kernel<float>, dim3((B + 3) / 4), dim3(256), 0, st, out, out_stride, (const float*)label, uid,
+                               delta, n_delta, alpha, B, T, loss_sum, dout, dout_stride, ddelta, err);
+        return hipGetLastError();
+    }
     if (label_is_f64)
         hipLaunchKernelGGL(loss_kernel<double>, dim3((B + 3) / 4), dim3(256), 0, st, out, out_stride, (const double*)label, uid, delta,
                            n_delta, alpha, B, T, loss_sum, dout, dout_stride, ddelta, err);

@@ -269,11 +269,13 @@ __global__ __launch_bounds__(THREADS, 4) void bwd_dz_rows_kernel(float* __restri
                         hi[e] = __builtin_bit_cast(unsigned short, hb);
                         lo[e] = __builtin_bit_cast(unsigned short, lb);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(
+                    // (both stores through the guard of common.hpp: their soffset is a literal 0 today, which hipcc pads by itself --
+                    // ADVICE r4 -- but the library's rule is that no 16-byte buffer store relies on that)
+                    store_b128_guarded(
                         u32x4{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16),
-                              (unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16)}, rz, off, 0, 0);
+                              (unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16)}, rz, off, 0);
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dz), rz, off, 0, 0);
+                    store_b128_guarded(__builtin_bit_cast(u32x4, dz), rz, off, 0);
                 }
                 av += dz;
                 acc[u] += dz;

@@ -252,12 +252,5 @@ class UserModel(nn.Module):
         return self.out_mlp(self.mlp(gated)).reshape(B, T)
 
     def loss(self, id, out, label, alpha=0.95):
-        if out.shape[1] <= 256:
-            return ops.softmax_bce_loss(out, self.delta, label, id, alpha)
-        # more than 256 candidates per impression: the reference formula on device tensors
-        ops._require_gpu(out)
-        y = label.to(torch.float32)
-        plain = self.bce_loss(self.softmax(out), y)
-        shifted = out + self.delta[id].unsqueeze(1)
-        personal = self.bce_loss(self.softmax(shifted), y)
-        return (1 - alpha) * plain + alpha * personal
+        # any number of candidates: one wave per impression, in registers up to T = 256, re-reading the row beyond (csrc/pool_loss.hip)
+        return ops.softmax_bce_loss(out, self.delta, label, id, alpha)

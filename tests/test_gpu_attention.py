@@ -83,8 +83,8 @@ def test_scores_and_grads_match_oracle(lib, B, T, H, D):
         assert rel_err(got[k], ref[k]) < GRAD_TOL, k
 
 
-# compact candidate image of the forward kernel (template parameter CT, csrc/pwattn_fwd.hip; default for H >= 16 on the 10 / 12 / 13 /
-# 16-tile plans): forced on from H = 5 and off, the scores and the saved pre-activation must be BIT-identical (same arithmetic, only
+# compact candidate image of the forward kernel (template parameter CT, csrc/pwattn_fwd.hip; default for H >= 16 on the 10 / 12 / 13-tile
+# plans -- the 16-tile plan of D = 768 keeps the per-row image, pwattn_fwd_launch measured it slower there): forced on from H = 5 and off, the scores and the saved pre-activation must be BIT-identical (same arithmetic, only
 # the LDS staging of the candidate rows differs) -- ragged row counts, blocks that span many candidates, D of every such plan
 @pytest.mark.parametrize("B,T,H,D", [(2, 30, 50, 400), (3, 7, 19, 388), (1, 64, 128, 768), (5, 3, 5, 160), (4, 9, 7, 192), (2, 11, 16, 400),
                                      (3, 5, 130, 208), (1, 1, 5, 400), (7, 2, 21, 176), (2, 13, 63, 768)])
@@ -108,9 +108,11 @@ def test_compact_candidate_image_is_bit_identical(lib, monkeypatch, B, T, H, D):
     assert rel_err(out["1"][0].cpu().numpy(), ref.numpy()) < FWD_TOL
 
 
-# full-row form of the dz pass (bwd_dz_rows_kernel: one workgroup owns all D columns of an impression; default only for B >= 512,
-# i.e. reached by the full-size tests alone): forced here on the small shapes it can take -- (D, H) -> 512 threads with <= 6 rows
-# per thread, else 1024 threads; shapes it cannot take (D = 768 / H = 128: 26 rows per thread) silently stay on the slab form
+# full-row form of the dz pass (bwd_dz_rows_kernel: one workgroup owns all D columns of an impression; the default from B >= 32 when
+# >= 85 % of the lanes own a column and a thread owns <= 6 rows, dz_rows_threads in csrc/pwattn_bwd.hip): forced here on every small
+# shape it can take -- (D, H) -> 512 threads with <= 6 rows per thread, else 1024 threads; shapes it cannot take (D = 768 / H = 128:
+# 26 rows per thread) silently stay on the slab form.  The DEFAULT dispatch (no NRM_DZ_ROWS / NRM_FWD_CT in the environment) is
+# asserted against the oracle by test_default_dispatch_at_batch_32_matches_oracle below
 DZ_ROWS_SHAPES = [(2, 30, 50, 400), (2, 30, 32, 256), (2, 15, 200, 64), (2, 20, 10, 256), (3, 7, 19, 72), (1, 1, 1, 64), (5, 1, 3, 64),
                   (7, 5, 37, 100), (1, 5, 17, 388), (1, 4, 9, 420), (2, 5, 7, 66), (3, 2, 4, 5), (1, 3, 300, 64), (2, 2, 520, 8),
                   (1, 64, 128, 768), (4, 3, 6, 1024), (2, 31, 5, 16)]
@@ -134,6 +136,25 @@ def test_full_row_dz_pass_matches_oracle_and_slab_form(lib, monkeypatch, mma, B,
         assert rel_err(got[k], ref[k]) < grad_tol, (k, rel_err(got[k], ref[k]))
         # same arithmetic per element; only the order of the dv / dw2 partial sums (and of float atomics downstream) differs
         assert rel_err(got[k], slab[k]) < 2e-5, (k, rel_err(got[k], slab[k]))
+
+
+@pytest.mark.parametrize("mma", ["f32", "bf16x3"])
+@pytest.mark.parametrize("B,T,H,D", [(32, 6, 16, 400), (33, 5, 50, 256), (40, 4, 24, 64)])
+def test_default_dispatch_at_batch_32_matches_oracle(lib, monkeypatch, mma, B, T, H, D):
+    """What the library picks BY ITSELF for B >= 32, H >= 16 (every other small test forces a form): the full-row dz pass
+    and, in fp32 at D = 400, the compact candidate image of the forward -- no NRM_DZ_ROWS / NRM_FWD_CT in the environment."""
+    for e in ("NRM_DZ_ROWS", "NRM_FWD_CT", "NRM_FWD_WALK", "NRM_BWD_RW", "NRM_DW_R32"):
+        monkeypatch.delenv(e, raising=False)
+    rng = np.random.default_rng(B * 1000 + T * 100 + H * 10 + D + 1)
+    w = _weights(rng, D)
+    tgt = rng.standard_normal((B, T, D)).astype(np.float32)
+    his = rng.standard_normal((B, H, D)).astype(np.float32)
+    gs = rng.standard_normal((B, T, H)).astype(np.float32)
+    s, got, s_ref, ref = _run_both(w, tgt, his, gs, mma=mma)
+    fwd_tol, grad_tol = (FWD_TOL, GRAD_TOL) if mma == "f32" else (1e-4, 1e-3)
+    assert rel_err(s, s_ref) < fwd_tol
+    for k in ref:
+        assert rel_err(got[k], ref[k]) < grad_tol, (k, rel_err(got[k], ref[k]))
 
 
 # bf16 MFMA operands, fp32 accumulation (BASELINE config 2).  Gates are the same as for the fp32 path and are taken against

@@ -76,6 +76,44 @@ def test_predict_follows_test_py_semantics(lib):
     assert abs(auc_v - want_auc) < 1e-5 and abs(tpr_v - want_tpr) < 1e-9
 
 
+@pytest.mark.parametrize("name", ["refdefault_eval", "c2_small_eval", "c3_large_eval"])
+def test_eval_forward_at_baseline_dims_matches_reference_fixture(lib, name):
+    """The part of inference that is pinned: model.eval() forward of the imported REFERENCE at BASELINE
+    dimensions on candidate lists with trailing all-zero padding (oracle/make_golden.py EVAL_CASES: logits `r` and
+    nn.Softmax(dim=1)(r), reference test.py:44,61).  (1) the Module's eval forward, (2) evaluation.predict with one model and
+    no declared padding -- exactly test.py:61's `softmax(model(...))` -- and (3) predict with the padding declared: its
+    pre-wrapper logits are the reference's on the live columns (a candidate's logit does not depend on the other candidates in
+    eval mode).  The trim / second softmax wrapped around them (test.py:48-56,:66-70) stays parity UNPINNED: checked here only
+    against numpy arithmetic on the reference's logits."""
+    from news_recommendation_model_amd import evaluation, trainer
+    case, dims, batch, sd, fx = load_case(name)
+    model = trainer.build_model(dims, int(batch["user_num"]), sd, device="cuda").eval()
+    tb = trainer.batch_to_device(batch, "cuda")
+    with torch.no_grad():
+        r = model(tb["x_history"], tb["x_target"], tb["x_global"])
+    assert rel_err(r.cpu().numpy(), fx["r"]) < 1e-3
+    assert np.abs(torch.softmax(r, dim=1).cpu().numpy() - fx["softmax_r"]).max() < 1e-3 * fx["softmax_r"].max()
+    # predict(), padding not declared: the reference's softmax(model(x)) line, one model
+    nopad = dict(tb, empty_num=torch.zeros(case["B"], dtype=torch.int64))
+    scores, live = evaluation.predict([model], nopad)
+    assert scores.shape == fx["softmax_r"].shape and bool((live == case["T"]).all())
+    assert np.abs(scores.cpu().numpy() - fx["softmax_r"]).max() < 1e-3 * fx["softmax_r"].max()
+    # predict(), padding declared (common to all rows -> trimmed before the forward): logits of the live columns
+    k = case["pad_target"]
+    scores_t, live_t = evaluation.predict([model], tb)
+    assert scores_t.shape[1] == case["T"] - k and bool((live_t == case["T"] - k).all())
+    live_logits = fx["r"][:, :case["T"] - k].astype(np.float64)
+    e = np.exp(live_logits - live_logits.max(1, keepdims=True))
+    want = e / e.sum(1, keepdims=True)
+    assert np.abs(scores_t.cpu().numpy() - want).max() < 1e-3 * want.max()
+    # and in the arithmetic BASELINE config 2 names (bf16 matrix cores on hi/lo split operands) where the case is that config
+    if name == "c2_small_eval":
+        m2 = trainer.build_model(dims, int(batch["user_num"]), sd, device="cuda", attention_mma="bf16x3").eval()
+        with torch.no_grad():
+            r2 = m2(tb["x_history"], tb["x_target"], tb["x_global"])
+        assert rel_err(r2.cpu().numpy(), fx["r"]) < 1e-3
+
+
 def test_graphed_predict_follows_weight_changes(lib, tmp_path):
     """a captured predict() reads the packed weight images that ops._pack filled BEFORE the capture.  Weights that
     change afterwards -- load_state_dict of another checkpoint, a torch.optim step, FlatAdam (which re-seats the parameters), a

@@ -10,7 +10,12 @@ The CPU oracle cannot run B=1024 (19.7 GB of concat per attention), so:
      the full batch == the mean of the gradients of its two halves (the halves are below the counting-sort threshold, so this
      also holds the sort against the atomic scatter at scale);
   2. train mode: the gradients and four optimizer steps of the DEFAULT big-batch paths against the same model with every such
-     path forced to its small-batch form, and against the captured step;
+     path forced to its small-batch form, and against the captured step.  This is a SELF-comparison (two summation orders of
+     the same arithmetic); every tolerance is computed from measured quantities by a stated error model (`_reorder_tol`,
+     `_one_step_bounds`), none is tuned.  It does NOT pin the two instant-interest gradients: at these weights the bias
+     gradient (1.4e-8, one live ReLU unit) is 3e-6 of its term-magnitude sum S, i.e. BELOW the fp32 noise any evaluation order
+     is allowed (golden_util.II_NOISE * S), so the derived gate cannot tell it from zero -- those two tensors are pinned by the
+     fixture tests (|gradient| / S = 1e-4 .. 1e-3 there), by the mutation test of tests/test_gpu_model.py and by test 3 below;
   3. the first train step at B=256 (the largest the oracle does in seconds) against the oracle on every output: the numbers
      bench.py prints as `hip_vs_oracle_first_step`, asserted (<= 1e-3 forward, <= 1e-2 gradients).
 """
@@ -25,6 +30,73 @@ pytestmark = pytest.mark.gpu
 FWD_TOL, GRAD_TOL = 1e-3, 1e-2
 B, H, T, D = 1024, 50, 30, 400
 PATH_ENVS = ("NRM_FE_SORT", "NRM_WGRAD_STREAM", "NRM_BRANCH_STREAMS")
+EPS32 = float(np.finfo(np.float32).eps)
+# Error model of the self-comparisons.  Every weight-gradient entry is a sum over the R = B*T head rows (x H for the attention
+# weights, whose per-row terms are themselves sums) evaluated in fp32; two orders of such a sum (float atomics, split slabs,
+# two streams) differ by a random walk of roundings: ~ eps * sqrt(R) * (magnitude of the partial sums).  The partial sums of
+# an entry are bounded by a few times the tensor's largest entry (NOISE_EPS: "a few eps", the same allowance
+# golden_util.II_NOISE makes per unit of term-magnitude sum), and a difference of two evaluations doubles it.
+NOISE_EPS = 5.0
+BC = 256                     # impressions of the oracle pass that supplies the instant-interest term-magnitude sums
+
+
+def _reorder_tol(rows):
+    """Relative (to max|g|) difference allowed between two fp32 summation orders of a gradient over ``rows`` rows."""
+    return 2.0 * NOISE_EPS * EPS32 * float(np.sqrt(rows))
+
+
+def _ii_bounds_scaled(sd, batch):
+    """Per-entry allowance for the two instant-interest gradients of the B-row batch, from ONE fp32 oracle pass over its first BC
+    impressions (golden_util.oracle_step_with_bounds: term-magnitude sums S of the same arithmetic; gradients are means, so S does
+    not grow with the batch) -- II_NOISE * S is what a single evaluation at BC*T rows may be off by; the random walk grows with
+    sqrt(rows), and a difference of two evaluations doubles it."""
+    from golden_util import II_NOISE
+    from bench import host_cores
+    sub = {k: (v[:BC] if isinstance(v, np.ndarray) and v.ndim > 0 and v.shape[0] == B else v) for k, v in batch.items()}
+    prev = torch.get_num_threads()
+    torch.set_num_threads(host_cores())
+    try:
+        bounds = oracle_step_with_bounds(sd, sub, dtype=torch.float32)[3]
+    finally:
+        torch.set_num_threads(prev)
+    scale = 2.0 * float(np.sqrt(B / BC)) * II_NOISE
+    return {k: torch.as_tensor(scale * v, dtype=torch.float32, device="cuda") for k, v in bounds.items()}
+
+
+SLACK = 2.0      # the Lipschitz estimates below are first order in delta
+
+
+def _one_step_bounds(opt, g_flat, delta_flat):
+    """Two Adam(lr, weight_decay) steps (train.py:48,73-75) from the SAME weights and moments whose gradients agree to ``delta``
+    per entry -> per-entry bounds on how far apart they land (``opt`` = the run taken as reference, AFTER its step k):
+
+        m_k = b1 m + (1 - b1) g                     |dm| <= (1 - b1) delta
+        v_k = b2 v + (1 - b2) g^2                   |dv| <= (1 - b2) (2 |g| + delta) delta
+        u   = lr m^ / (sqrt(v^) + eps)              |du| <= lr min(2, 2 delta / (sqrt(v^) + eps))
+
+    (u is +-lr wherever the sign of the gradient is determined and Lipschitz there: dm^/sqrt(v^) + m^ d sqrt(v^)/v^ with
+    |m^| <= sqrt(v^) up to the bias corrections and d sqrt(v^) <= delta |g| / sqrt(v^); an entry within delta of zero may take
+    either sign: 2 lr.)  SLACK covers the second-order terms.  g includes the weight decay term (same weights on both sides)."""
+    b1, b2 = opt.betas
+    vhat = opt.exp_avg_sq / (1.0 - b2 ** opt.steps)
+    du = opt.lr * torch.clamp(2.0 * delta_flat / (vhat.sqrt() + opt.eps), max=2.0)
+    dm = (1.0 - b1) * delta_flat
+    dv = (1.0 - b2) * (2.0 * g_flat.abs() + delta_flat) * delta_flat
+    certain = vhat.sqrt() >= 100.0 * delta_flat           # the update is pinned to <= 2 % of lr there
+    return SLACK * du, SLACK * dm, SLACK * dv, certain
+
+
+def _state(model, opt):
+    return {"p": opt.flat_param.clone(), "m": opt.exp_avg.clone(), "v": opt.exp_avg_sq.clone(), "s": opt.state.clone(),
+            "bn": {k: v.clone() for k, v in model.bn.state_dict().items()}}
+
+
+def _load_state(model, opt, st):
+    """In place (addresses stay what a captured graph baked in); the packed GEMM operands are images of the weights."""
+    from news_recommendation_model_amd import ops
+    opt.flat_param.copy_(st["p"]); opt.exp_avg.copy_(st["m"]); opt.exp_avg_sq.copy_(st["v"]); opt.state.copy_(st["s"])
+    model.bn.load_state_dict(st["bn"])
+    ops.repack_persistent(opt.params)
 
 
 def _setup(batch_size=B, seed=3, perturb=True):
@@ -77,7 +149,8 @@ def test_full_size_c3_eval_bn_model_properties(lib, monkeypatch):
             assert float(g[k].abs().max()) < 1e-5 * max(1.0, gscale), k
             continue
         err = float((g[k] - want).abs().max())
-        assert err <= 2e-4 * float(want.abs().max()) + 1e-6 * gscale, (k, err, float(want.abs().max()))
+        # two evaluations of a sum over B*T rows in different orders (whole batch vs mean of halves; sort vs scatter): _reorder_tol
+        assert err <= _reorder_tol(B * T) * float(want.abs().max()) + 1e-6 * gscale, (k, err, float(want.abs().max()))
     # two impressions against the oracle (eval mode: the running statistics of the state dict)
     idx = [7, 901]
     p = orc.to_torch_params(sd, requires_grad=False)
@@ -129,44 +202,92 @@ def test_full_size_c3_train_step_big_batch_paths_match_their_small_batch_forms(l
     assert torch.allclose(out_b, out_s, rtol=1e-5, atol=1e-6)
     assert abs(loss_b - loss_s) <= 1e-5 * abs(loss_s)          # (logits agree to rounding: float atomics in the pooled rows' order)
     gscale = max(float(v.abs().max()) for v in g_s.values())
-    for k in g_s:
+    ii = _ii_bounds_scaled(sd, batch)
+    rel = _reorder_tol(B * T)                                  # 2 * 5 eps * sqrt(30 720) = 2.1e-4
+    for i, k in enumerate(g_s):
+        diff = (g_b[k] - g_s[k]).abs()
         if k in ZERO_GRAD_KEYS:
             assert float(g_b[k].abs().max()) < 1e-5 * max(1.0, gscale), k
-            continue
-        # same kernels up to the order of float atomics; the two instant-interest tensors are cancellation residues (the bias: 1e-3
-        # of its term sum), which the order of a 30 720-row reduction moves by more than 1e-4 of the residue itself
-        # (measured over 12 runs: the bias differs by 5.1-5.2 % of its 1.4e-8 maximum between the two reduction orders; the gates
-        # that pin this gradient are the fixture tests and the B = 256 oracle test below, with their derived bounds)
-        tol = (0.3 if k == II_B else 1e-2 if k == II_W else 2e-4) * float(g_s[k].abs().max()) + 1e-7 * gscale
-        assert float((g_b[k] - g_s[k]).abs().max()) <= tol, (k, float((g_b[k] - g_s[k]).abs().max()), float(g_s[k].abs().max()))
-    # (c) four optimizer steps: small-batch forms (eager), default paths (eager), default paths (3 warm-up steps + one replay of
-    # the captured step) -- same losses, same place in weight space
-    p0 = {k: v.detach().clone() for k, v in small.named_parameters()}
-    losses_s = [float(trainer.train_step(small, sopt, tb, defer_reductions=False)[0]) for _ in range(4)]
-    for e in PATH_ENVS:
-        monkeypatch.delenv(e, raising=False)
-    losses_b = [float(trainer.train_step(big, bopt, tb)[0]) for _ in range(4)]
+            tol = torch.full_like(g_s[k], 1e-5 * max(1.0, gscale))
+        else:
+            # same kernels up to the order of float atomics (_reorder_tol); the two instant-interest tensors are cancellation
+            # residues whose noise is set by their term-magnitude sums, not by their own size (_ii_bounds_scaled)
+            tol = torch.full_like(g_s[k], rel * float(g_s[k].abs().max()) + EPS32 * gscale)
+            if k in ii:
+                tol = tol + ii[k].reshape(tol.shape)
+            assert bool((diff <= tol).all()), (k, float(diff.max()), float(g_s[k].abs().max()), float(tol.max()))
+    # (c) four optimizer steps in LOCK-STEP: before every step the default-path model takes over the small-form model's weights,
+    # Adam moments, step counter and BatchNorm statistics, both take the step, and everything they produce is compared under the
+    # one-step bounds of _one_step_bounds.  (Round 4 let the two runs drift freely for four steps: in this regime -- the logits
+    # grow 10x per step, the reference's arithmetic does the same, tests/golden traj_c3 -- sign flips of noise-level gradients are
+    # amplified chaotically, and the only tolerances that passed were tuned ones.)  Same weights -> the loss agrees to rounding;
+    # the updates, both moments and the BatchNorm statistics agree entry by entry within what the gradient agreement allows.
+    names = [k for k, _ in small.named_parameters()]
+    assert names == [k for k, _ in big.named_parameters()] and sopt.offsets == bopt.offsets
+
+    def gradient_agreement(g_flat, first):
+        """Per-entry delta of this step: _reorder_tol of every tensor's own maximum; the zero-gradient keys and -- after the first
+        step, where their term-magnitude sums were taken -- the two instant-interest tensors count as undetermined (their
+        entries may take either sign: 2 lr)."""
+        d = torch.full_like(g_flat, float("inf"))             # (the 16-byte alignment gaps between tensors: never compared)
+        gs = float(g_flat.abs().max())
+        for i, k in enumerate(names):
+            o, n = sopt.offsets[i], sopt.params[i].numel()
+            if k in ZERO_GRAD_KEYS or (k in ii and not first):
+                d[o:o + n] = float("inf")
+            else:
+                d[o:o + n] = rel * float(g_flat[o:o + n].abs().max()) + EPS32 * gs
+                if k in ii:
+                    d[o:o + n] += ii[k].reshape(-1)
+        return d
+
+    def compare(other, oopt, g_flat, first, what):
+        du, dm, dv, certain = _one_step_bounds(sopt, g_flat + sopt.weight_decay * before["p"], gradient_agreement(g_flat, first))
+        tiny = EPS32 * before["p"].abs() + 1e-12
+        for got, ref, bound, name in ((oopt.flat_param, sopt.flat_param, du, "weights"), (oopt.exp_avg, sopt.exp_avg, dm, "exp_avg"),
+                                      (oopt.exp_avg_sq, sopt.exp_avg_sq, dv, "exp_avg_sq")):
+            excess = ((got - ref).abs() - torch.nan_to_num(bound, posinf=3.0e38) - (tiny if name == "weights" else 1e-30))
+            worst = int(excess.argmax())
+            assert float(excess[worst]) <= 0, (what, name, worst, float((got - ref).abs()[worst]), float(bound[worst]))
+        for key in ("running_mean", "running_var"):           # same inputs, same previous statistics: rounding only
+            assert rel_err(getattr(other.bn, key).cpu().numpy(), getattr(small.bn, key).cpu().numpy()) < 1e-5, (what, key)
+        return certain
+
+    for step_no in range(4):
+        before = _state(small, sopt)
+        _load_state(big, bopt, before)
+        monkeypatch.setenv("NRM_FE_SORT", "0")
+        monkeypatch.setenv("NRM_WGRAD_STREAM", "0")
+        monkeypatch.setenv("NRM_BRANCH_STREAMS", "0")
+        out = small(tb["x_history"], tb["x_target"], tb["x_global"])
+        loss = small.loss(tb["user_id"], out, tb["label"])
+        loss.backward()
+        sopt.collect_grads()
+        g_step = sopt.flat_grad.clone()
+        sopt.step(zero_grad=True)
+        for e in PATH_ENVS:
+            monkeypatch.delenv(e, raising=False)
+        ls, lb = float(loss.detach()), float(trainer.train_step(big, bopt, tb)[0])
+        assert abs(lb - ls) <= 1e-5 * abs(ls), (step_no, ls, lb)
+        certain = compare(big, bopt, g_step, step_no == 0, f"eager step {step_no}")
+        assert bopt.steps == sopt.steps == step_no + 1
+    # the gate is a real one: most updates of the big dense tensors are pinned to <= 2 % of lr (clearly signed gradients)
+    dense = [i for i, k in enumerate(names) if sopt.params[i].numel() >= 10000 and k not in ZERO_GRAD_KEYS]
+    fracs = {names[i]: float(certain[sopt.offsets[i]:sopt.offsets[i] + sopt.params[i].numel()].float().mean()) for i in dense}
+    total = sum(fracs[names[i]] * sopt.params[i].numel() for i in dense) / sum(sopt.params[i].numel() for i in dense)
+    print("full-size lock-step: fraction of clearly signed entries, dense tensors:", round(total, 4), {k: round(v, 3) for k, v in fracs.items()})
+    assert total > 0.5, (total, fracs)
+    # the captured step: 3 warm-up steps + capture on its own weights, then ONE replay from the small-form model's state before
+    # its fourth step, against that fourth step
     graphed, gopt = fresh()
     step = trainer.GraphedTrainStep(graphed, gopt, tb, warmup=3)
+    _load_state(graphed, gopt, before)
     loss_g, _ = step.replay()
     torch.cuda.synchronize()
     ops.check_index_errors("cuda")
-    assert gopt.steps == bopt.steps == sopt.steps == 4
-    for a, b_ in zip(losses_s, losses_b):
-        assert abs(a - b_) <= 3e-4 * abs(a), (losses_s, losses_b)
-    assert abs(float(loss_g) - losses_s[3]) <= 3e-4 * abs(losses_s[3])
-    for other in (big, graphed):
-        for (k, ps), (_, po) in zip(small.named_parameters(), other.named_parameters()):
-            if k in ZERO_GRAD_KEYS or ps.numel() <= 8:
-                continue
-            move = float((ps - p0[k]).norm())
-            # a tensor moves ~ sqrt(n) * 4 lr in norm; ONE entry whose near-zero gradient took the other sign for one step (atomic
-            # order decides it) moves 2 lr the other way: the allowance golden_util.check_trajectory gives small tensors
-            tol = max(2e-2, 2.5 / (np.sqrt(ps.numel()) * 4))
-            assert float((po - ps).norm()) <= tol * move + 1e-7, (k, float((po - ps).norm()), move, tol)
-    for other in (big, graphed):          # four updates of the running statistics (norm-wise: tiny entries follow the weights' sign noise)
-        assert rel_err(other.bn.running_mean.cpu().numpy(), small.bn.running_mean.cpu().numpy()) < 1e-3
-        assert rel_err(other.bn.running_var.cpu().numpy(), small.bn.running_var.cpu().numpy()) < 1e-3
+    assert gopt.steps == sopt.steps == 4
+    assert abs(float(loss_g) - ls) <= 1e-5 * abs(ls), (float(loss_g), ls)
+    compare(graphed, gopt, g_step, False, "captured step")
 
 
 def test_c3_first_train_step_at_batch_256_matches_the_oracle(lib, monkeypatch):

@@ -24,6 +24,9 @@ def test_oracle_matches_fixture(name):
         assert rel_err(r.numpy(), fx["r"]) < 1e-5
         assert abs(float(loss) - float(fx["loss"])) < 1e-6
         assert rel_err(aux["eu_H"].numpy(), fx["eu_H"]) < 1e-5
+        if "softmax_r" in fx.files:                # BASELINE-dims eval cases (round 5): test.py:61's softmax(model(x)) of the reference
+            assert np.abs(torch.softmax(r, dim=1).numpy() - fx["softmax_r"]).max() < 1e-6
+            assert rel_err(aux["ec"].numpy(), fx["ec"]) < 1e-5
         return
     p = orc.to_torch_params(sd)
     opt_state = {"step": 0, "m": {}, "v": {}}
