@@ -248,27 +248,32 @@ def validate_batch_ids(model, batch):
     (time4 | text_img[P] | category | sub-categories | sentiment | type ...: models/user_invariant_interest_model.py:14-22,58-71)
     and every user id (models/user_model.py:40; negative ids count from the end, as torch indexing does) is range-checked on the
     device; ONE host synchronisation.  The asynchronous default is IndexErrorWatch."""
+    if torch.cuda.is_current_stream_capturing():
+        # the check ends in ONE host read of a device flag: inside a stream capture that is an error that can take the process
+        # down (global capture mode).  A captured step cannot raise per replay anyway: validate before capturing / replaying.
+        raise RuntimeError("validate_batch_ids / train_step(strict_ids=True) synchronises with the host and cannot run inside a "
+                           "stream capture; validate the batch before the capture (or rely on IndexErrorWatch around replays)")
     inv = model.invariant_interest_model
     d = inv._dims
     P, ns = d.pca_vector, d.n_subcat
-    bad = torch.zeros((), dtype=torch.bool, device=batch["x_history"].device)
-    tables = (inv.year_embedding[0].num_embeddings, inv.month_embedding[0].num_embeddings, inv.day_embedding[0].num_embeddings,
-              inv.hour_embedding[0].num_embeddings)
+    dev = batch["x_history"].device
+    tables = torch.tensor([inv.year_embedding[0].num_embeddings, inv.month_embedding[0].num_embeddings,
+                           inv.day_embedding[0].num_embeddings, inv.hour_embedding[0].num_embeddings], device=dev)
     n_cat, n_type = inv.category_embedding[0].num_embeddings, inv.type_embedding[0].num_embeddings
+    flags = []
     for x in (batch["x_history"], batch["x_target"]):
         if x.numel() == 0:
             continue
-        for c, n in enumerate(tables):
-            col = x[..., c].long()
-            bad |= ((col < 0) | (col >= n)).any()                        # (F.embedding refuses negative indices too)
+        t4 = x[..., :4].long()                                           # the four time-table indices of a row, one comparison
+        flags.append(((t4 < 0) | (t4 >= tables)).any())                  # (F.embedding refuses negative indices too)
         ids = x[..., 4 + P:4 + P + 1 + ns].long()                     # category and its sub-category slots share one table
-        bad |= ((ids < 0) | (ids >= n_cat)).any()
+        flags.append(((ids < 0) | (ids >= n_cat)).any())
         typ = x[..., 4 + P + 1 + ns + d.n_sentiment].long()
-        bad |= ((typ < 0) | (typ >= n_type)).any()
+        flags.append(((typ < 0) | (typ >= n_type)).any())
     n = model.delta.numel()
     uid = batch["user_id"].long()
-    bad |= ((uid < -n) | (uid >= n)).any()
-    if bool(bad):                                                      # the one synchronisation
+    flags.append(((uid < -n) | (uid >= n)).any())
+    if bool(torch.stack(flags).any()):                                 # the one synchronisation
         raise IndexError("index out of range in self (a category / type / time table index of a packed feature row, or a user id "
                          "outside delta); nothing was enqueued, no weight was updated")
 

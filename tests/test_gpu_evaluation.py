@@ -262,6 +262,14 @@ def test_train_epochs_raises_indexerror_for_an_out_of_range_id(lib):
         trainer.train_step(model, opt, bad_uid, strict_ids=True)
     trainer.train_step(model, opt, trainer.batch_to_device(hosts[0], "cuda"), strict_ids=True)     # a clean batch passes
     ops.check_index_errors("cuda")
+    # ... and it says so instead of breaking a stream capture (its one host read of a device flag)
+    clean = trainer.batch_to_device(hosts[0], "cuda")
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="cannot run inside a stream capture"):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            trainer.validate_batch_ids(model, clean)
+    torch.cuda.synchronize()
     # the asynchronous watch says what it could not prevent
     trainer.train_step(model, opt, bad)
     torch.cuda.synchronize()
