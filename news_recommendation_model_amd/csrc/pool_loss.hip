@@ -8,6 +8,7 @@
 //   loss_kernel: one wave per impression; softmax max/sum and the row reductions are wave shuffles; writes the
 //   loss partial sum and, analytically, dL/dout and dL/ddelta (BCELoss clamps log at -100; its gradient uses
 //   (p - y) / max(p (1 - p), 1e-12) like torch.nn.BCELoss).
+#include <cstdlib>
 #include "common.hpp"
 #include "pool_loss.hpp"
 
@@ -18,17 +19,23 @@ namespace nrm {
 // MFMA columns = the slab's columns in the interleaved order of the backward contractions (lane r16 holds columns
 // 4*r16 + tile of the four column tiles), so ONE 16-byte load of X[j][4*r16 .. +3] feeds four MFMAs and a lane's four
 // results of one output row are consecutive columns (float4 store).  Rows / columns past the edge read as 0.
+// JSPLIT (round 5): with few (impression, slab, row group) tasks -- the reference's default sizes have 256: one wave each, walking
+// J = 200 history rows in 50 dependent load -> MFMA rounds, 93 us for 0.1 GFLOP -- the four waves of a workgroup share ONE task,
+// each takes a quarter of the reduction range and waves 1-3 hand their partial tiles to wave 0 through the LDS.  Either way the
+// operands of round j0 + 4 are requested before the MFMAs of round j0.
+template <bool JSPLIT>
 __global__ __launch_bounds__(256) void bmm_rows_kernel(const float* __restrict__ W, long wsb, long wsi, long wsj,
                                                        const float* __restrict__ X, long xsb, int ldx,
                                                        float* __restrict__ out, long osb, int ldo,
                                                        int B, int I, int J, int D, int accumulate) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) f32x4 part[JSPLIT ? 3 * 16 * 64 : 1];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, q = lane >> 4;
     const int nslab = (D + 63) >> 6, nig = (I + 63) >> 6;
-    const long task = (long)blockIdx.x * 4 + wave;
-    if (task >= (long)B * nslab * nig) return;
+    const long task = JSPLIT ? (long)blockIdx.x : (long)blockIdx.x * 4 + wave;
+    if (task >= (long)B * nslab * nig) return;                         // (JSPLIT: the whole workgroup leaves together)
     const int slab = (int)(task % nslab);
     const int ig = (int)((task / nslab) % nig);
     const int b = (int)(task / ((long)nslab * nig));
@@ -44,20 +51,49 @@ __global__ __launch_bounds__(256) void bmm_rows_kernel(const float* __restrict__
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) acc[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nit = min(4, (I - i0 + 15) >> 4);                         // uniform: live row tiles of this group
-    for (int j0 = 0; j0 < J; j0 += 4) {
+    // reduction range of this wave: everything, or its quarter (in whole rounds of 4 rows)
+    const int jq = JSPLIT ? ((J + 15) >> 4) * 4 : J;
+    const int j_lo = JSPLIT ? wave * jq : 0, j_hi = min(J, j_lo + jq);
+    auto load = [&](int j0, f32x4& x4, float (&a)[4]) {
         const int j = j0 + q;
-        const f32x4 x4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vx, j0 * ldx * 4, 0));  // rows >= J: 0
-        float a[4];
+        x4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vx, j0 * ldx * 4, 0));  // rows >= J: 0
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int i = i0 + 16 * it + r16;
-            a[it] = (it < nit && i < I && j < J) ? Wb[(long)i * wsi + (long)j * wsj] : 0.f;
+            a[it] = (it < nit && i < I && j < j_hi) ? Wb[(long)i * wsi + (long)j * wsj] : 0.f;
         }
+    };
+    f32x4 x_cur, x_nxt;
+    float a_cur[4], a_nxt[4];
+    if (j_lo < j_hi) load(j_lo, x_cur, a_cur);
+    for (int j0 = j_lo; j0 < j_hi; j0 += 4) {
+        if (j0 + 4 < j_hi) load(j0 + 4, x_nxt, a_nxt);
 #pragma unroll
         for (int it = 0; it < 4; ++it)
             if (it < nit)
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt) acc[it][jt] = mfma16(a[it], x4[jt], acc[it][jt]);
+                for (int jt = 0; jt < 4; ++jt) acc[it][jt] = mfma16(a_cur[it], x_cur[jt], acc[it][jt]);
+        x_cur = x_nxt;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) a_cur[it] = a_nxt[it];
+    }
+    if (JSPLIT) {
+        if (wave > 0) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                if (it < nit)
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) part[((wave - 1) * 16 + it * 4 + jt) * 64 + lane] = acc[it][jt];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                if (it < nit)
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) acc[it][jt] += part[(w * 16 + it * 4 + jt) * 64 + lane];
     }
     // lane holds acc[it][jt][e] = out[i0 + 16it + 4q + e][d0 + 4*r16 + jt]
     if (d0 + 4 * r16 < D) {
@@ -156,8 +192,15 @@ hipError_t bmm_rows_launch(const float* W, long wsb, long wsi, long wsj, const f
     if (B <= 0 || I <= 0) return hipSuccess;
     const long tasks = (long)B * ((D + 63) / 64) * ((I + 63) / 64);
     if ((tasks + 3) / 4 > 0x7fffffffL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(bmm_rows_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, st,
-                       W, wsb, wsi, wsj, X, xsb, ldx, out, osb, ldo, B, I, J, D, accumulate);
+    // fewer tasks than wave slots worth filling and a reduction long enough to cut in four: one workgroup per task (NRM_POOL_JSPLIT=0|1 forces)
+    const char* env = getenv("NRM_POOL_JSPLIT");
+    const bool jsplit = env ? env[0] == '1' : (tasks < 4096 && J >= 32);
+    if (jsplit)
+        hipLaunchKernelGGL(bmm_rows_kernel<true>, dim3((unsigned)tasks), dim3(256), 0, st,
+                           W, wsb, wsi, wsj, X, xsb, ldx, out, osb, ldo, B, I, J, D, accumulate);
+    else
+        hipLaunchKernelGGL(bmm_rows_kernel<false>, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, st,
+                           W, wsb, wsi, wsj, X, xsb, ldx, out, osb, ldo, B, I, J, D, accumulate);
     return hipGetLastError();
 }
 

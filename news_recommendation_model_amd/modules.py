@@ -143,6 +143,13 @@ class UserInvariantInterestModel(nn.Module):
                             self.day_embedding[0].weight, self.hour_embedding[0].weight)
 
     def forward(self, x_history, x_target):
+        pooled_lab, pooled_ti, lab_t, ti_t = self.forward_parts(x_history, x_target)
+        return ops.concat_last((pooled_lab, pooled_ti)), ops.concat_last((lab_t, ti_t))       # (eu_H, ec): :81,:88
+
+    def forward_parts(self, x_history, x_target):
+        """The four column blocks of forward()'s two results -- eu_H = [pooled_lab | pooled_ti], ec = [lab_t | ti_t] -- before their
+        concatenation: UserModel.forward writes them into the head's [eu_H | eu_L | ec] rows with ONE launch instead of three
+        (two here, one there: 0.14 ms of a 31 ms step at C3, 50 us of 3.2 ms at C2)."""
         ops._require_gpu(x_history, x_target)
         if x_history.shape[0] * x_history.shape[1] == 0 or x_target.shape[1] == 0:
             # same error as the reference, whose feature_embedding reshapes with a -1 dimension (:59); the ops below
@@ -155,7 +162,6 @@ class UserInvariantInterestModel(nn.Module):
             self.type_embedding[0].weight, self.year_embedding[0].weight, self.month_embedding[0].weight,
             self.day_embedding[0].weight, self.hour_embedding[0].weight)
         lab_h = ops.linear(lab_h, self.w1.weight, self.w1.bias)
-        ec = ops.concat_last((lab_t, ti_t))
 
         # The two attentions (label features / text+image vector) share no data until the concat, so the second one is issued on
         # a side stream and overlaps the first -- in eager mode and as two parallel branches of the captured HIP graph; autograd
@@ -176,7 +182,7 @@ class UserInvariantInterestModel(nn.Module):
         else:
             pooled_lab = self._attend_and_pool(self.label_attention, lab_t, lab_h)
             pooled_ti = self._attend_and_pool(self.text_img_attention, ti_t, ti_h)
-        return ops.concat_last((pooled_lab, pooled_ti)), ec
+        return pooled_lab, pooled_ti, lab_t, ti_t
 
     @staticmethod
     def _attend_and_pool(attention, t, h):
@@ -238,9 +244,16 @@ class UserModel(nn.Module):
         self.softmax = nn.Softmax(dim=1)
 
     def forward(self, x_history, x_target, x_global):
-        eu_H, ec = self.invariant_interest_model(x_history, x_target)
-        eu_L = self.instant_interest_model(x_global)
-        e = ops.concat_last((eu_H, eu_L, ec))
+        inv = self.invariant_interest_model
+        if type(inv) is UserInvariantInterestModel and not (inv._forward_hooks or inv._forward_pre_hooks):
+            # e = cat[eu_H, eu_L, ec] (:31) with eu_H and ec never materialised on their own: one concat launch of five blocks
+            pooled_lab, pooled_ti, lab_t, ti_t = inv.forward_parts(x_history, x_target)
+            eu_L = self.instant_interest_model(x_global)
+            e = ops.concat_last((pooled_lab, pooled_ti, eu_L, lab_t, ti_t))
+        else:                                   # a hooked / substituted sub-model is called as the reference calls it (:28)
+            eu_H, ec = inv(x_history, x_target)
+            eu_L = self.instant_interest_model(x_global)
+            e = ops.concat_last((eu_H, eu_L, ec))
         B, T, N = e.shape
         rows = e.reshape(B * T, N)
         g = self.gate

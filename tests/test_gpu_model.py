@@ -279,11 +279,19 @@ def test_mlp_with_a_non_default_activation_matches_the_reference_formula(lib, ac
         assert rel_err(v.grad.cpu().numpy(), w[k].grad.numpy()) < 1e-4, k
 
 
-def test_pool_kernels_match_bmm(lib):
+@pytest.mark.parametrize("jsplit", [None, "0", "1"])
+def test_pool_kernels_match_bmm(lib, monkeypatch, jsplit):
+    """bmm_rows_kernel / rowdot_kernel against torch.bmm in float64; the pool's batched GEMM in both forms -- one wave per task
+    and (round 5) one WORKGROUP per task with the reduction range cut in four (what few-task shapes such as the reference's
+    default sizes take by themselves) -- and as dispatched (None)."""
     from news_recommendation_model_amd import ops
+    if jsplit is None:
+        monkeypatch.delenv("NRM_POOL_JSPLIT", raising=False)
+    else:
+        monkeypatch.setenv("NRM_POOL_JSPLIT", jsplit)
     torch.manual_seed(1)
     for B, T, H, D in ((3, 5, 7, 64), (2, 30, 50, 400), (1, 9, 130, 100), (2, 3, 5, 30), (2, 17, 70, 36), (1, 33, 64, 20),
-                       (5, 16, 65, 132), (1, 1, 1, 4)):
+                       (5, 16, 65, 132), (1, 1, 1, 4), (4, 15, 200, 64), (2, 70, 33, 72), (3, 2, 3, 8)):
         s = torch.randn(B, T, H, device="cuda", requires_grad=True)
         h = torch.randn(B, H, D, device="cuda", requires_grad=True)
         g = torch.randn(B, T, D, device="cuda")
