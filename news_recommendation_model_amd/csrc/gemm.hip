@@ -107,12 +107,18 @@ hipError_t pack_rows_launch(const float* src, long rs, long cs, int nrows, int n
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NT, int MT, int EPI, int WPE = 2>
+// KC (round 5): 16-wide K-chunks per LDS stage.  A launch of few workgroups (the head of C1: 5120 rows = 80 row blocks) has one
+// or two workgroups per CU, nothing co-resident to hide a stage's DMA latency behind, and with one chunk per stage a chain of
+// K/16 rounds of (DMA ~1.5 us  ||  52 MFMAs = 0.7 us) + barrier: latency-bound at a third of the MFMA rate.  KC = 2 / 4 puts two /
+// four consecutive chunks into one stage (the packed operand and the X rows are already laid out chunk after chunk): a quarter
+// of the rounds and barriers, 70 / 139 KB of LDS -- which such a launch has to spare.  Big grids keep KC = 1 (four workgroups per CU).
+template <int NT, int MT, int EPI, int WPE = 2, int KC = 1>
 __global__ __launch_bounds__(256, WPE) void gemm_nt_kernel(const GemmNtParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = 4 * MT * 16;
     constexpr int WROWS = NT * 16;
-    constexpr int BUF = (WROWS + BM) * 16;                           // [W chunk | X rows], 16 floats per row
+    constexpr int SUB = (WROWS + BM) * 16;                           // one 16-wide chunk: [W chunk | X rows], 16 floats per row
+    constexpr int BUF = KC * SUB;
     __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
 
     const int tid = threadIdx.x;
@@ -165,6 +171,12 @@ __global__ __launch_bounds__(256, WPE) void gemm_nt_kernel(const GemmNtParams p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(buf + (WROWS + (wave * MT + j) * 16) * 16),
                                                      16, voff_x[j], c * 64, 0, 0);
     };
+    // stage s = chunks KC*s .. KC*s + KC - 1 (those that exist)
+    auto dma_stage = [&](int s, float* buf) {
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+            if (KC == 1 || s * KC + k < p.kchunks) dma_chunk(s * KC + k, buf + k * SUB);
+    };
     // FULL = false: column tiles >= ntv -- the zero padding of the last N-chunk (3 of 13 tiles at N = 1608, 1 of 13 at N = 400) --
     // issue no MFMA: 3-4 % of the launch at those widths.  (The zero padding of the last K-chunk cannot be skipped the same way:
     // K-step j of a chunk covers k = 4 q + j over the four lane groups q -- the 16-byte fragment layout -- so at K = 402 every
@@ -192,15 +204,20 @@ __global__ __launch_bounds__(256, WPE) void gemm_nt_kernel(const GemmNtParams p)
     };
 
     const int nt_valid = min(NT, (p.N - n0 + 15) >> 4);              // (workgroup-uniform)
-    dma_chunk(0, smem);
+    const int nstages = (p.kchunks + KC - 1) / KC;
+    dma_stage(0, smem);
     __syncthreads();
     if (NRM_PRIO) __builtin_amdgcn_s_setprio(NRM_PRIO);
-    for (int c = 0; c < p.kchunks; ++c) {
+    for (int c = 0; c < nstages; ++c) {
         float* cur = smem + (c & 1) * BUF;
         float* nxt = smem + ((c & 1) ^ 1) * BUF;
-        if (c + 1 < p.kchunks && !(NRM_DIAG_GEMM & 4)) dma_chunk(c + 1, nxt);
-        if (nt_valid == NT) compute(cur, std::true_type{}, NT);
-        else compute(cur, std::false_type{}, nt_valid);
+        if (c + 1 < nstages && !(NRM_DIAG_GEMM & 4)) dma_stage(c + 1, nxt);
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            if (KC > 1 && c * KC + k >= p.kchunks) break;
+            if (nt_valid == NT) compute(cur + k * SUB, std::true_type{}, NT);
+            else compute(cur + k * SUB, std::false_type{}, nt_valid);
+        }
         if (!(NRM_DIAG_GEMM & 1)) __syncthreads();
     }
     if (NRM_PRIO) __builtin_amdgcn_s_setprio(0);
@@ -272,15 +289,19 @@ GemmNtPlan gemm_nt_plan(int N) {
     return pl;
 }
 
-template <int NT, int MT, int WPE = 2>
+template <int NT, int MT, int WPE = 2, int KC = 1>
 static hipError_t launch_nt(const GemmNtParams& p, const GemmNtPlan& pl, int epi, hipStream_t st) {
     constexpr int BM = 4 * MT * 16;
     const dim3 grid((p.M + BM - 1) / BM, pl.nchunks), block(256);
+    if (KC > 1) {                                                    // more than 64 KB of static LDS: opt in once per kernel and device
+        constexpr int lds = 2 * KC * (NT * 16 + BM) * 16 * 4;
+        static_assert(lds <= 160 * 1024, "two stages must fit the CU's LDS");
+    }
     switch (epi) {
-        case EPI_BIAS:  hipLaunchKernelGGL((gemm_nt_kernel<NT, MT, EPI_BIAS, WPE>), grid, block, 0, st, p); break;
-        case EPI_GELU:  hipLaunchKernelGGL((gemm_nt_kernel<NT, MT, EPI_GELU, WPE>), grid, block, 0, st, p); break;
-        case EPI_DGELU: hipLaunchKernelGGL((gemm_nt_kernel<NT, MT, EPI_DGELU, WPE>), grid, block, 0, st, p); break;
-        case EPI_MUL:   hipLaunchKernelGGL((gemm_nt_kernel<NT, MT, EPI_MUL, WPE>), grid, block, 0, st, p); break;
+        case EPI_BIAS:  hipLaunchKernelGGL((gemm_nt_kernel<NT, MT, EPI_BIAS, WPE, KC>), grid, block, 0, st, p); break;
+        case EPI_GELU:  hipLaunchKernelGGL((gemm_nt_kernel<NT, MT, EPI_GELU, WPE, KC>), grid, block, 0, st, p); break;
+        case EPI_DGELU: hipLaunchKernelGGL((gemm_nt_kernel<NT, MT, EPI_DGELU, WPE, KC>), grid, block, 0, st, p); break;
+        case EPI_MUL:   hipLaunchKernelGGL((gemm_nt_kernel<NT, MT, EPI_MUL, WPE, KC>), grid, block, 0, st, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -294,6 +315,28 @@ hipError_t gemm_nt_launch(const GemmNtParams& p, const GemmNtPlan& pl, int epi, 
     // take one row tile per wave instead.  NRM_NT_SMALLM=0 keeps the planned MT.
     static const bool small_m = [] { const char* e = getenv("NRM_NT_SMALLM"); return !(e && e[0] == '0'); }();
     const long wgs = (long)((p.M + 64 * pl.MT - 1) / (64 * pl.MT)) * pl.nchunks;
+    // Few workgroups AND a reduction of several stages: deeper stages (template parameter KC).  wgs1 = the grid with one row tile per
+    // wave; <= 512 of them (two per CU) take two chunks per stage, <= 256 four.  NRM_NT_KC=1|2|4 forces (1 = the round-4 kernels).
+    const char* kc_e = getenv("NRM_NT_KC");                           // (read per launch: tests switch forms inside one process)
+    const int kc_env = kc_e ? atoi(kc_e) : 0;
+    const long wgs1 = (long)((p.M + 63) / 64) * pl.nchunks;
+    int kc = kc_env ? kc_env : (wgs1 <= 256 ? 4 : wgs1 <= 512 ? 2 : 1);
+    if (p.kchunks < 2 * kc) kc = p.kchunks >= 4 ? 2 : 1;             // (p.kchunks = ceil(K / 16))
+    if (kc > 1 && (pl.MT == 1 || (small_m && wgs < 512))) {
+        if (kc == 4) {
+            if (pl.NT == 4) return launch_nt<4, 1, 1, 4>(p, pl, epi, st);
+            if (pl.NT == 5) return launch_nt<5, 1, 1, 4>(p, pl, epi, st);
+            if (pl.NT == 8) return launch_nt<8, 1, 1, 4>(p, pl, epi, st);
+            if (pl.NT == 9) return launch_nt<9, 1, 1, 4>(p, pl, epi, st);
+            if (pl.NT == 13) return launch_nt<13, 1, 1, 4>(p, pl, epi, st);
+        } else {
+            if (pl.NT == 4) return launch_nt<4, 1, 2, 2>(p, pl, epi, st);
+            if (pl.NT == 5) return launch_nt<5, 1, 2, 2>(p, pl, epi, st);
+            if (pl.NT == 8) return launch_nt<8, 1, 2, 2>(p, pl, epi, st);
+            if (pl.NT == 9) return launch_nt<9, 1, 2, 2>(p, pl, epi, st);
+            if (pl.NT == 13) return launch_nt<13, 1, 2, 2>(p, pl, epi, st);
+        }
+    }
     if (small_m && pl.MT > 1 && wgs < 512) {
         if (pl.NT == 4) return launch_nt<4, 1, 4>(p, pl, epi, st);
         if (pl.NT == 5) return launch_nt<5, 1, 4>(p, pl, epi, st);

@@ -35,6 +35,41 @@ def test_linear_forward_backward(lib, M, K, N, gelu):
     assert rel_err(bg.grad.cpu().numpy(), br.grad.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("M,K,N", [(5120, 1032, 258), (5120, 258, 1032), (3840, 264, 66), (300, 402, 1608), (257, 1608, 402), (33, 66, 64),
+                                   (64, 3, 8), (700, 400, 402), (20000, 402, 400)])
+def test_gemm_nt_stage_depths_are_bit_identical(lib, monkeypatch, M, K, N):
+    """gemm_nt_kernel<..., KC>: one, two or four 16-wide K-chunks per LDS stage (round 5: launches of few workgroups -- the heads of
+    C1 and of the reference's default sizes -- take the deeper stages by themselves).  The chunks are contracted in the same order
+    whatever the stage depth, so forward, input gradient and the GELU / GELU' epilogues must agree bit for bit with KC = 1 (the
+    round-4 kernel, which the float64 comparisons of this file were written against); K / 16 not a multiple of KC, fewer chunks
+    than one stage, a grid that would not pick KC by itself."""
+    from news_recommendation_model_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / np.sqrt(K)).cuda()
+    b = (torch.randn(N, generator=g) * 0.1).cuda()
+    gy = torch.randn(M, N, generator=g).cuda()
+    out = {}
+    for kc in ("1", "2", "4", None):
+        if kc is None:
+            monkeypatch.delenv("NRM_NT_KC", raising=False)
+        else:
+            monkeypatch.setenv("NRM_NT_KC", kc)
+        res = []
+        for gelu in (False, True):
+            xg = x.clone().requires_grad_(True)
+            y = ops.linear(xg, w, b, gelu=gelu)
+            y.backward(gy)
+            res += [y.detach().clone(), xg.grad.clone()]
+        torch.cuda.synchronize()
+        out[kc] = res
+    for kc in ("2", "4", None):
+        for a, r in zip(out[kc], out["1"]):
+            assert torch.equal(a, r), (kc, float((a - r).abs().max()))
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    assert rel_err(out[None][0].cpu().numpy(), ref.cpu().numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("M,K,Hd,N", [(300, 1608, 402, 1608), (257, 1608, 402, 1), (64, 264, 66, 264), (33, 72, 18, 5),
                                       (7, 16, 4, 3), (1000, 256, 64, 1)])
 def test_mlp_gelu_forward_backward(lib, M, K, Hd, N):

@@ -248,7 +248,8 @@ def test_full_size_c3_train_step_big_batch_paths_match_their_small_batch_forms(l
         tiny = EPS32 * before["p"].abs() + 1e-12
         for got, ref, bound, name in ((oopt.flat_param, sopt.flat_param, du, "weights"), (oopt.exp_avg, sopt.exp_avg, dm, "exp_avg"),
                                       (oopt.exp_avg_sq, sopt.exp_avg_sq, dv, "exp_avg_sq")):
-            excess = ((got - ref).abs() - torch.nan_to_num(bound, posinf=3.0e38) - (tiny if name == "weights" else 1e-30))
+            # (+ one rounding of the result itself: two fma results whose exact values are closer than an ulp can still differ by one)
+            excess = ((got - ref).abs() - torch.nan_to_num(bound, posinf=3.0e38) - (tiny if name == "weights" else EPS32 * ref.abs() + 1e-30))
             worst = int(excess.argmax())
             assert float(excess[worst]) <= 0, (what, name, worst, float((got - ref).abs()[worst]), float(bound[worst]))
         for key in ("running_mean", "running_var"):           # same inputs, same previous statistics: rounding only
