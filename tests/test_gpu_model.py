@@ -172,8 +172,7 @@ def test_loss_kernel_matches_oracle_including_clamp(lib):
 def test_loss_kernel_beyond_256_candidates_matches_oracle(lib, monkeypatch):
     """reference models/user_model.py:37-43 takes any number of candidates.  Up to 256 a lane holds its four candidates in
     registers; beyond, loss_long_kernel re-reads the row in every pass (round 4 ran ATen ops there: VERDICT r4 'missing' 4).
-    (1) Forced onto rows of <= 256 candidates (NRM_LOSS_LONG=1) it must reproduce the register kernel BIT FOR BIT -- value, dL/dout,
-    dL/ddelta, contiguous and padded [B*T, 4] logits, incl. the -100 clamp regime (where the gradient of the dominant candidate is a
+    (1) Forced onto rows of <= 256 candidates (NRM_LOSS_LONG=1) it must reproduce the register kernel -- dL/dout BIT FOR BIT, the value and dL/ddelta up to the order of their float atomics --, contiguous and padded [B*T, 4] logits, incl. the -100 clamp regime (where the gradient of the dominant candidate is a
     cancellation residue and only a bitwise comparison means anything).  (2) T = 300 / 1000 against the oracle.  (3) UserModel.loss."""
     from news_recommendation_model_amd import ops, trainer
     from news_recommendation_model_amd.config import Dims
@@ -208,8 +207,9 @@ def test_loss_kernel_beyond_256_candidates_matches_oracle(lib, monkeypatch):
             reg = run(out, label, uid, delta, padded)
             monkeypatch.setenv("NRM_LOSS_LONG", "1")
             lng = run(out, label, uid, delta, padded)
-            for a, r, name in zip(lng, reg, ("loss", "dout", "ddelta")):
-                assert torch.equal(a, r), (T, scale, padded, name)
+            assert torch.equal(lng[1], reg[1]), (T, scale, padded, "dout")        # per row: no atomics, bit for bit
+            # the batch sum of the loss and rows that share a user id are float atomics: the same numbers in another order
+            assert torch.allclose(lng[0], reg[0], rtol=1e-6, atol=0) and torch.allclose(lng[2], reg[2], rtol=1e-5, atol=1e-12), (T, scale, padded)
     monkeypatch.delenv("NRM_LOSS_LONG", raising=False)
     for B, T, scale in ((5, 300, 1.0), (3, 1000, 2.0), (4, 257, 4.0)):
         out, label, uid, delta = make(B, T, scale)
