@@ -209,7 +209,8 @@ def test_loss_kernel_beyond_256_candidates_matches_oracle(lib, monkeypatch):
             lng = run(out, label, uid, delta, padded)
             assert torch.equal(lng[1], reg[1]), (T, scale, padded, "dout")        # per row: no atomics, bit for bit
             # the batch sum of the loss and rows that share a user id are float atomics: the same numbers in another order
-            assert torch.allclose(lng[0], reg[0], rtol=1e-6, atol=0) and torch.allclose(lng[2], reg[2], rtol=1e-5, atol=1e-12), (T, scale, padded)
+            # (dL/ddelta is zero in exact arithmetic -- softmax is shift invariant -- so what is compared is a residue of roundings)
+            assert torch.allclose(lng[0], reg[0], rtol=1e-6, atol=0) and float((lng[2] - reg[2]).abs().max()) < 1e-7 * float(reg[1].abs().max()) * T, (T, scale, padded)
     monkeypatch.delenv("NRM_LOSS_LONG", raising=False)
     for B, T, scale in ((5, 300, 1.0), (3, 1000, 2.0), (4, 257, 4.0)):
         out, label, uid, delta = make(B, T, scale)
