@@ -315,12 +315,13 @@ hipError_t gemm_nt_launch(const GemmNtParams& p, const GemmNtPlan& pl, int epi, 
     // take one row tile per wave instead.  NRM_NT_SMALLM=0 keeps the planned MT.
     static const bool small_m = [] { const char* e = getenv("NRM_NT_SMALLM"); return !(e && e[0] == '0'); }();
     const long wgs = (long)((p.M + 64 * pl.MT - 1) / (64 * pl.MT)) * pl.nchunks;
-    // Few workgroups AND a reduction of several stages: deeper stages (template parameter KC).  wgs1 = the grid with one row tile per
-    // wave; <= 512 of them (two per CU) take two chunks per stage, <= 256 four.  NRM_NT_KC=1|2|4 forces (1 = the round-4 kernels).
+    // Deeper LDS stages (template parameter KC = 2 | 4 chunks per stage) for launches of few workgroups: built on the theory that
+    // such a launch is a chain of DMA-latency-bound rounds, measured (graph replay, same box, whole step): C1 1.795 -> 1.84 ms
+    // (gemm_nt 33.2 -> 35.3 us per launch), reference default 12.9 -> 12.2 us per launch -- the latency chain is not what limits
+    // these launches.  Not a default: NRM_NT_KC=2|4 selects it (tests hold every depth bit-identical to KC = 1).
     const char* kc_e = getenv("NRM_NT_KC");                           // (read per launch: tests switch forms inside one process)
-    const int kc_env = kc_e ? atoi(kc_e) : 0;
-    const long wgs1 = (long)((p.M + 63) / 64) * pl.nchunks;
-    int kc = kc_env ? kc_env : (wgs1 <= 256 ? 4 : wgs1 <= 512 ? 2 : 1);
+    int kc = kc_e ? atoi(kc_e) : 1;
+    if (kc != 2 && kc != 4) kc = 1;
     if (p.kchunks < 2 * kc) kc = p.kchunks >= 4 ? 2 : 1;             // (p.kchunks = ceil(K / 16))
     if (kc > 1 && (pl.MT == 1 || (small_m && wgs < 512))) {
         if (kc == 4) {

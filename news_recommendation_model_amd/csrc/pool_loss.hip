@@ -192,9 +192,11 @@ hipError_t bmm_rows_launch(const float* W, long wsb, long wsi, long wsj, const f
     if (B <= 0 || I <= 0) return hipSuccess;
     const long tasks = (long)B * ((D + 63) / 64) * ((I + 63) / 64);
     if ((tasks + 3) / 4 > 0x7fffffffL) return hipErrorInvalidValue;
-    // fewer tasks than wave slots worth filling and a reduction long enough to cut in four: one workgroup per task (NRM_POOL_JSPLIT=0|1 forces)
+    // few tasks (one wave each would leave most SIMDs empty) and a reduction long enough to cut in four: one workgroup per task.
+    // Measured (graph replay, same box): reference default sizes, 256 tasks, J = 200: 27.8 -> 14.8 us per launch; C2, 2048 tasks,
+    // J = 32: 18.6 -> 22.4 us -- so only up to 1024 tasks.  NRM_POOL_JSPLIT=0|1 forces either form.
     const char* env = getenv("NRM_POOL_JSPLIT");
-    const bool jsplit = env ? env[0] == '1' : (tasks < 4096 && J >= 32);
+    const bool jsplit = env ? env[0] == '1' : (tasks <= 1024 && J >= 32);
     if (jsplit)
         hipLaunchKernelGGL(bmm_rows_kernel<true>, dim3((unsigned)tasks), dim3(256), 0, st,
                            W, wsb, wsi, wsj, X, xsb, ldx, out, osb, ldo, B, I, J, D, accumulate);

@@ -38,8 +38,8 @@ def test_linear_forward_backward(lib, M, K, N, gelu):
 @pytest.mark.parametrize("M,K,N", [(5120, 1032, 258), (5120, 258, 1032), (3840, 264, 66), (300, 402, 1608), (257, 1608, 402), (33, 66, 64),
                                    (64, 3, 8), (700, 400, 402), (20000, 402, 400)])
 def test_gemm_nt_stage_depths_are_bit_identical(lib, monkeypatch, M, K, N):
-    """gemm_nt_kernel<..., KC>: one, two or four 16-wide K-chunks per LDS stage (round 5: launches of few workgroups -- the heads of
-    C1 and of the reference's default sizes -- take the deeper stages by themselves).  The chunks are contracted in the same order
+    """gemm_nt_kernel<..., KC>: one, two or four 16-wide K-chunks per LDS stage (round 5: built for launches of few workgroups -- the
+    heads of C1 and of the reference's default sizes --, measured no faster there, kept behind NRM_NT_KC).  The chunks are contracted in the same order
     whatever the stage depth, so forward, input gradient and the GELU / GELU' epilogues must agree bit for bit with KC = 1 (the
     round-4 kernel, which the float64 comparisons of this file were written against); K / 16 not a multiple of KC, fewer chunks
     than one stage, a grid that would not pick KC by itself."""
@@ -50,7 +50,7 @@ def test_gemm_nt_stage_depths_are_bit_identical(lib, monkeypatch, M, K, N):
     b = (torch.randn(N, generator=g) * 0.1).cuda()
     gy = torch.randn(M, N, generator=g).cuda()
     out = {}
-    for kc in ("1", "2", "4", None):
+    for kc in ("1", "2", "4", None):              # None: the default dispatch (KC = 1 since the measurement of round 5)
         if kc is None:
             monkeypatch.delenv("NRM_NT_KC", raising=False)
         else:
