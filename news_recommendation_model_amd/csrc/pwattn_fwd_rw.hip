@@ -398,6 +398,130 @@ __global__ __launch_bounds__(512, 2) void pwattn_fwd_walk_kernel(const FwdParams
 #endif
 }
 
+// The same walk on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32, the fp32 image of pack_wp_kernel: 16-column chunks), round 5, for
+// the widths whose whole W_p is one resident slice and whose h / u rows fit the registers beside the accumulators (D = 64: the
+// reference's default sizes, configs/model_config.py:29; D = 128).  The tile-by-tile kernel above re-loads h, u and the fc2
+// weights for every candidate: 24 vector-memory instructions per 64 MFMAs at D = 64, 0.113 ms per launch at the reference's default
+// sizes (0.35 of the fp32 MFMA peak) for 0.04 ms of MFMA work and 0.033 ms of z store.  Here a wave keeps its 16 history rows (D / 4
+// floats per lane), its u tile and the fc2 weights in registers and walks the candidates: 4 t loads (two chunks ahead, across step
+// boundaries), NTS v loads and NTS z stores per step.  Same arithmetic per element as the kernel above (accumulators start at u, v
+// is added in the epilogue: (u + P W_p^T) + v instead of (u + v) + P W_p^T -- one fp32 rounding apart).
+template <int NTS, bool SAVE_Z, int KCH>
+__global__ __launch_bounds__(512, 2) void pwattn_fwd_walk_f32_kernel(const FwdParams p, const RwPlan pl, int wgs, int tsplit) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(KCH % 2 == 0 && NTS == KCH, "whole width in one slice: D = 16 KCH = 16 NTS");
+    constexpr int SROWS = NTS * 16;
+    constexpr int NW = 8;
+    extern __shared__ __attribute__((aligned(16))) float wres[];       // [KCH][SROWS][16 floats]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int T = p.T, H = p.H, D = p.D;
+
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, p.wp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w2), 0, D * 4, 0x00020000);
+    for (int pc = wave; pc < KCH * NTS; pc += NW) {
+        const int c = pc / NTS, rt = pc - c * NTS;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(wres + pc * 256), 16, lane * 16,
+                                                 (c * pl.rows + rt * 16) * 64, 0, 0);
+    }
+    __syncthreads();
+
+    const int rslot = 4 * (q ^ swz4(r16));
+    const float b2 = p.b2[0];
+    const int nht = (H + 15) >> 4;
+    const int tlen = (T + tsplit - 1) / tsplit;
+    const int ntask = (int)(p.M / ((long)T * H)) * nht * tsplit;         // B * nht * tsplit
+    f32x4 wreg[NTS];                                                     // fc2 weights of this lane's four columns of every tile
+#pragma unroll
+    for (int it = 0; it < NTS; ++it)
+        wreg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, 16 * q, it * 64, 0));
+
+    for (int task = blockIdx.x * NW + wave; task < ntask; task += wgs * NW) {
+        const int tp = task % tsplit;
+        const int rest = task / tsplit;
+        const int b = rest / nht, h0 = (rest - b * nht) * 16;
+        const int t_lo = tp * tlen, t_hi = min(T, t_lo + tlen);
+        if (t_lo >= t_hi) continue;
+        const bool rok = h0 + r16 < H;
+        const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.t) + (size_t)b * T * p.ldt, 0, (unsigned)(T * p.ldt * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v) + (size_t)b * T * p.ldv, 0, (unsigned)(T * p.ldv * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.h) + (size_t)b * H * p.ldh, 0, (unsigned)(H * p.ldh * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u) + (size_t)b * H * p.ldu, 0, (unsigned)(H * p.ldu * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(
+            SAVE_Z ? p.z + (size_t)b * T * H * D : nullptr, 0, SAVE_Z ? (unsigned)((size_t)T * H * D * 4) : 0, 0x00020000);
+
+        // once per task: this lane's h row (its 4 reduction columns of every chunk) and u row (its 4 columns of every tile)
+        f32x4 hreg[KCH], ureg[NTS];
+        const unsigned vh = rok ? (unsigned)(((h0 + r16) * p.ldh + 4 * q) * 4) : OOB;
+        const unsigned vu = rok ? (unsigned)(((h0 + r16) * p.ldu + 4 * q) * 4) : OOB;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) hreg[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, vh, c * 64, 0));
+#pragma unroll
+        for (int it = 0; it < NTS; ++it) ureg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, vu, it * 64, 0));
+
+        // t operand ring: chunk c of a step lives in slot c & 1 and is requested two chunks ahead (KCH is even)
+        f32x4 tr[2];
+        const unsigned vt = (unsigned)(4 * q * 4);
+        auto load_t = [&](int slot, int t, int c) {
+            tr[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_t, vt, t * p.ldt * 4 + c * 64, 0));
+        };
+        load_t(0, t_lo, 0);
+        load_t(1, t_lo, 1);
+        const unsigned vv_off = (unsigned)(4 * q * 4);
+        const unsigned vz = rok ? (unsigned)(((h0 + r16) * D + 4 * q) * 4) : OOB;
+
+        for (int t = t_lo; t < t_hi; ++t) {
+            f32x4 acc[NTS];
+#pragma unroll
+            for (int it = 0; it < NTS; ++it) acc[it] = ureg[it];
+            // this candidate's v segments: requested before the MFMAs, consumed in the epilogue
+            f32x4 vreg[NTS];
+#pragma unroll
+            for (int it = 0; it < NTS; ++it)
+                vreg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, vv_off, t * p.ldv * 4 + it * 64, 0));
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+                const int slot = c & 1;
+                const f32x4 pf = tr[slot] * hreg[c];                    // this lane's 4 reduction columns of P[m,:] = t * h
+                {
+                    const int cn = c + 2;
+                    const int tn = t + (cn >= KCH ? 1 : 0);
+                    if (tn < t_hi) load_t(slot, tn, cn >= KCH ? cn - KCH : cn);
+                }
+                const float* buf = wres + c * (SROWS * 16);
+                auto rd = [&](int it) { return *reinterpret_cast<const f32x4*>(&buf[(it * 16 + r16) * 16 + rslot]); };
+                f32x4 af = rd(0);
+#pragma unroll
+                for (int it = 0; it < NTS; ++it) {
+                    f32x4 afn = af;
+                    if (it + 1 < NTS) afn = rd(it + 1);                 // one tile (4 MFMAs = 128 cycles) ahead
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[it] = mfma16(af[j], pf[j], acc[it]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    af = afn;
+                }
+            }
+            // epilogue: z = acc + v ; optional z store ; GELU ; fc2 dot
+            const int m = (b * T + t) * H + h0 + r16;
+            float s_part = 0.f;
+#pragma unroll
+            for (int it = 0; it < NTS; ++it) {
+                const f32x4 zz = acc[it] + vreg[it];
+                if (SAVE_Z) store_b128_guarded(__builtin_bit_cast(u32x4, zz), rs_z, vz, t * H * D * 4 + it * 64);
+                const f32x4 ww = wreg[it];
+                s_part += ww[0] * gelu_f(zz[0]) + ww[1] * gelu_f(zz[1]) + ww[2] * gelu_f(zz[2]) + ww[3] * gelu_f(zz[3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float sv = sum_rows4(s_part) + b2;
+            if (q == 0 && rok) p.s[m] = sv;
+        }
+    }
+#endif
+}
+
 static int rw_cus() {       // of the CURRENT device (a process may drive several): queried per launch, not cached
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
@@ -467,9 +591,36 @@ static hipError_t launch_walk(const FwdParams& p, const RwPlan& pl, int mma, hip
     return hipGetLastError();
 }
 
+template <int NTS>
+static hipError_t launch_walk_f32(const FwdParams& p, const RwPlan& pl, hipStream_t st) {
+    const int B = (int)(p.M / ((long)p.T * p.H)), nht = (p.H + 15) / 16;
+    const long base = (long)B * nht;
+    if (base <= 0) return hipSuccess;
+    int wgs = 2 * rw_cus();                                             // two workgroups of 8 waves per CU
+    int tsplit = 1;
+    if (const char* e = getenv("NRM_FWD_TSPLIT")) tsplit = atoi(e);
+    else while (base * tsplit < 2L * wgs * 8 && p.T / (tsplit + 1) >= 4) ++tsplit;
+    if (tsplit < 1) tsplit = 1;
+    if (tsplit > p.T) tsplit = p.T;
+    const long ntask = base * tsplit;
+    if ((long)wgs * 8 > ntask) wgs = (int)((ntask + 7) / 8);
+    const size_t shm = (size_t)pl.k32 * NTS * 1024;
+    const dim3 grid((unsigned)wgs), block(512);
+    if (p.z) hipLaunchKernelGGL((pwattn_fwd_walk_f32_kernel<NTS, true, NTS>), grid, block, shm, st, p, pl, wgs, tsplit);
+    else     hipLaunchKernelGGL((pwattn_fwd_walk_f32_kernel<NTS, false, NTS>), grid, block, shm, st, p, pl, wgs, tsplit);
+    return hipGetLastError();
+}
+
 hipError_t pwattn_fwd_rw_launch(const FwdParams& p, int mma, hipStream_t st) {
     const RwPlan pl = pwattn_rw_plan(p.D, mma);
     static const bool walk = [] { const char* e = getenv("NRM_FWD_WALK"); return !(e && e[0] == '0'); }();
+    // fp32: the walk for the widths that are one resident slice of whole 16-column tiles (NRM_FWD_WALK_F32=0|1 forces per launch)
+    if (mma == 0 && pl.nsplit == 1 && p.D == pl.nts * 16 && p.M % ((long)p.T * p.H) == 0 && (long)p.T * p.H * p.D * 4 < (1L << 31)) {
+        const char* e = getenv("NRM_FWD_WALK_F32");
+        if ((e ? e[0] == '1' : true) && p.D == 64) return launch_walk_f32<4>(p, pl, st);
+        // D = 128: h + u + accumulators + v take 196 VGPRs (two waves per SIMD): not the default, NRM_FWD_WALK_F32=1 selects it
+        if (e && e[0] == '1' && p.D == 128) return launch_walk_f32<8>(p, pl, st);
+    }
     if (walk && mma != 0 && p.M % ((long)p.T * p.H) == 0 && (long)p.T * p.H * p.D * 4 < (1L << 31)) {
         if (p.D == 256 && pl.nts == 8) return launch_walk<8, 8>(p, pl, mma, st);
         if (p.D == 128 && pl.nts == 8) return launch_walk<8, 4>(p, pl, mma, st);

@@ -83,6 +83,40 @@ def test_scores_and_grads_match_oracle(lib, B, T, H, D):
         assert rel_err(got[k], ref[k]) < GRAD_TOL, k
 
 
+# fp32 "walk" form of the resident-W forward (pwattn_fwd_walk_f32_kernel, round 5; the default at D = 64, NRM_FWD_WALK_F32=1 at D = 128):
+# a wave keeps its 16 history rows, its u tile and the fc2 weights in registers and walks the candidates.  Against the oracle and
+# against the tile-by-tile resident-W kernel (NRM_FWD_WALK_F32=0) -- scores and the saved pre-activation; the two start their
+# accumulators at u and at u + v, one fp32 rounding apart -- with and without the z store, ragged last history tile, a candidate
+# walk split over workgroups (few impressions), T = 1, H = 1
+@pytest.mark.parametrize("B,T,H,D", [(2, 15, 200, 64), (256, 15, 200, 64), (3, 7, 19, 64), (1, 1, 1, 64), (5, 1, 3, 64), (2, 33, 16, 64),
+                                     (1, 40, 17, 64), (2, 15, 50, 128), (3, 5, 9, 128)])
+def test_fp32_walk_forward_matches_oracle_and_tile_form(lib, monkeypatch, B, T, H, D):
+    from news_recommendation_model_amd import ops
+    rng = np.random.default_rng(B * 1000 + T * 100 + H * 10 + D + 3)
+    w = {k: torch.from_numpy(v).cuda() for k, v in _weights(rng, D).items()}
+    t = torch.from_numpy(rng.standard_normal((B, T, D)).astype(np.float32)).cuda()
+    h = torch.from_numpy(rng.standard_normal((B, H, D)).astype(np.float32)).cuda()
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("NRM_FWD_WALK_F32", mode)
+        s, z = ops.pwattn_fwd(t, h, w["mlp.fc1.weight"], w["mlp.fc1.bias"], w["mlp.fc2.weight"], w["mlp.fc2.bias"], True, ops.MMA_F32)
+        s2, _ = ops.pwattn_fwd(t, h, w["mlp.fc1.weight"], w["mlp.fc1.bias"], w["mlp.fc2.weight"], w["mlp.fc2.bias"], False, ops.MMA_F32)
+        torch.cuda.synchronize()
+        out[mode] = (s.clone(), z.clone(), s2.clone())
+    assert torch.equal(out["1"][0], out["1"][2])                      # the z store does not change the scores
+    assert torch.allclose(out["1"][1], out["0"][1], rtol=1e-5, atol=1e-5)      # z: (u + P W^T) + v against (u + v) + P W^T
+    assert torch.allclose(out["1"][0], out["0"][0], rtol=1e-4, atol=1e-5)
+    if B <= 8:
+        p = {"a." + k: v.cpu() for k, v in w.items()}
+        ref = orc.pointwise_attention_scores(p, "a", t.cpu(), h.cpu())[..., 0]
+        assert rel_err(out["1"][0].cpu().numpy(), ref.numpy()) < FWD_TOL
+        assert rel_err(out["0"][0].cpu().numpy(), ref.numpy()) < FWD_TOL
+    # the default dispatch: the walk at D = 64, the tile form at D = 128
+    monkeypatch.delenv("NRM_FWD_WALK_F32", raising=False)
+    s, _ = ops.pwattn_fwd(t, h, w["mlp.fc1.weight"], w["mlp.fc1.bias"], w["mlp.fc2.weight"], w["mlp.fc2.bias"], True, ops.MMA_F32)
+    assert torch.equal(s, out["1" if D == 64 else "0"][0])
+
+
 # compact candidate image of the forward kernel (template parameter CT, csrc/pwattn_fwd.hip; default for H >= 16 on the 10 / 12 / 13-tile
 # plans -- the 16-tile plan of D = 768 keeps the per-row image, pwattn_fwd_launch measured it slower there): forced on from H = 5 and off, the scores and the saved pre-activation must be BIT-identical (same arithmetic, only
 # the LDS staging of the candidate rows differs) -- ragged row counts, blocks that span many candidates, D of every such plan
