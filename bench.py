@@ -38,10 +38,10 @@ FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mf
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA (the 5 PF headline figure includes 2:1 sparsity)
 HBM_PEAK_GBS = 8000.0             # same guide: HBM3E spec peak (6.3 TB/s measured achievable)
 # (workload, dtype) -> committed rocprofv3 --pmc summary of the same bench command (scripts/collect_profiles.sh + pmc_summary.py)
-PMC_TRAFFIC_FILES = {("C3-large", "f32"): "r4_c3_pmc_traffic.json", ("C5-long", "f32"): "r4_c5_pmc_traffic.json",
-                     ("C2-small", "bf16x3"): "r4_c2_bf16x3_pmc_traffic.json", ("C1-demo", "f32"): "r4_c1_pmc_traffic.json",
-                     ("ref-default", "f32"): "r4_refdefault_pmc_traffic.json"}
-INFER_TRAFFIC_FILES = {("C3-large", "f32"): "r4_infer_c3_pmc_traffic.json"}
+PMC_TRAFFIC_FILES = {("C3-large", "f32"): "r5_c3_pmc_traffic.json", ("C5-long", "f32"): "r5_c5_pmc_traffic.json",
+                     ("C2-small", "bf16x3"): "r5_c2_bf16x3_pmc_traffic.json", ("C1-demo", "f32"): "r5_c1_pmc_traffic.json",
+                     ("ref-default", "f32"): "r5_refdefault_pmc_traffic.json"}
+INFER_TRAFFIC_FILES = {("C3-large", "f32"): "r5_infer_c3_pmc_traffic.json"}
 
 
 def parse():
