@@ -879,6 +879,9 @@ def main():
             "grad_allreduce_bytes": job["grad_allreduce_bytes"], "replicas_in_sync": job["replicas_in_sync"],
             "collective": job["collective"],
         }
+        # provenance: which kernel sources the loaded binary says it was built from, next to the sources this run sees
+        line["build"] = dict(native.provenance(), kernel_sources_sha256=_build.sources_digest())
+        line["build"]["match"] = line["build"]["library_sources_sha256"] == line["build"]["kernel_sources_sha256"]
         if pcie is not None:
             line["pcie_inclusive"] = pcie
         line["fwd_auc_parity"] = fwd_auc_parity(dev, args.dtype, {"C2-small": "c2_small", "C1-demo": "c1_demo", "C5-long": "c5_long",

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define NRM_ABI_VERSION 4
+#define NRM_ABI_VERSION 5
 #define NRM_OK 0
 #define NRM_EINVAL (-1)   /* bad shape / alignment / null pointer */
 #define NRM_ELAUNCH (-2)  /* HIP launch error */
@@ -30,6 +30,12 @@ const char* nrm_last_error(void);
  * (kernels with parts of their work removed: results are WRONG by construction); the Python binding refuses to load such a
  * library unless NRM_ALLOW_DIAG_LIB=1. */
 int nrm_build_flags(void);
+/* Provenance (round 5): the sha256 over the kernel sources (csrc/ and this header, news_recommendation_model_amd/build.py
+ * sources_digest()) this library was compiled from, and a one-line build record (compiler, flags, UTC time).  The Python
+ * binding refuses a library whose digest differs from the sources lying next to it (NRM_ALLOW_STALE_LIB=1 overrides), bench.py
+ * prints both, so a measured binary is tied to the sources it is shown with. */
+const char* nrm_source_digest(void);
+const char* nrm_build_info(void);
 
 /* ---- pointwise history attention: reference models/attention_model.py:52-97
  *      (PointwiseAttentionExpanded.forward), score[b,t,h] = fc2(GELU(fc1(cat[h,t,t-h,t*h]))).

@@ -41,12 +41,46 @@ def sources_digest():
     return h.hexdigest()
 
 
+def _provenance_object(hipcc, objdir, extra_flags):
+    """A generated translation unit (never part of the digest) that makes the library say what it was built from:
+    nrm_source_digest() = sources_digest() at build time, nrm_build_info() = compiler, flags, time."""
+    import datetime
+    ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.splitlines()
+    ver = next((ln.strip() for ln in ver if "HIP version" in ln or "clang version" in ln), "hipcc")
+    info = (f"{ver}; --offload-arch=gfx950 -O3 -std=c++17 -fPIC {' '.join(extra_flags)}".strip()
+            + f"; built {datetime.datetime.now(datetime.timezone.utc).strftime('%Y-%m-%dT%H:%M:%SZ')}")
+    src = os.path.join(objdir, "provenance.cpp")
+    with open(src, "w") as f:
+        f.write('extern "C" const char* nrm_source_digest(void) { return "%s"; }\n' % sources_digest())
+        f.write('extern "C" const char* nrm_build_info(void) { return "%s"; }\n' % info.replace("\\", "/").replace('"', "'"))
+    obj = os.path.join(objdir, "provenance.o")
+    subprocess.run([hipcc, "-O2", "-fPIC", "-c", src, "-o", obj], check=True)
+    return obj
+
+
+def library_digest(path=None):
+    """nrm_source_digest() of a built library without going through native.load (None: the library is missing or older than
+    the entry point)."""
+    import ctypes
+    path = path or LIB
+    if not os.path.exists(path):
+        return None
+    try:
+        lib = ctypes.CDLL(path)
+        lib.nrm_source_digest.restype = ctypes.c_char_p
+        return lib.nrm_source_digest().decode()
+    except (OSError, AttributeError):
+        return None
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "nrm_hotpath.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    if any(os.path.getmtime(d) > t for d in deps):
+        return True
+    return library_digest() != sources_digest()        # (modification times lie after a checkout or a copy: the content decides)
 
 
 def build(force=False, verbose=True, extra_flags=(), lib=None):
@@ -77,6 +111,7 @@ def build(force=False, verbose=True, extra_flags=(), lib=None):
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
+    objs.append(_provenance_object(hipcc, objdir, extra_flags))
     cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", out + ".tmp"]
     if verbose:
         print("[nrm build]", " ".join(cmd), flush=True)

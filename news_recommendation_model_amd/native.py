@@ -11,7 +11,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NRM_HOTPATH_LIB") or os.path.join(_HERE, "libnrm_hotpath.so")   # override: diagnostic builds (scripts/_diag)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c_fp = ctypes.c_void_p      # device pointers travel as integers
 _c_i, _c_l = ctypes.c_int, ctypes.c_long
@@ -21,6 +21,8 @@ SIGNATURES = {
     "nrm_abi_version": (_c_i, []),
     "nrm_last_error": (ctypes.c_char_p, []),
     "nrm_build_flags": (_c_i, []),
+    "nrm_source_digest": (ctypes.c_char_p, []),
+    "nrm_build_info": (ctypes.c_char_p, []),
     "nrm_pwattn_packed_floats": (_c_l, [_c_i]),
     "nrm_pwattn_pack_wp": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp]),
     "nrm_pwattn_fwd": (_c_i, [_c_fp] * 9 + [_c_i] * 5 + [_c_fp]),
@@ -109,8 +111,22 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} is a timing-diagnostic build (nrm_build_flags() = {flags:#x}: kernels with parts of their work "
                 "removed, results are wrong by construction); set NRM_ALLOW_DIAG_LIB=1 to load it for timing experiments")
+        # provenance: the binary must have been built from the kernel sources lying next to it (they travel with it to the GPU box)
+        if os.environ.get("NRM_ALLOW_STALE_LIB") != "1" and not os.environ.get("NRM_HOTPATH_LIB"):
+            from . import build as _build
+            if os.path.isdir(_build.CSRC):
+                have, want = lib.nrm_source_digest().decode(), _build.sources_digest()
+                if have != want:
+                    raise RuntimeError(f"{LIB_PATH} was built from other kernel sources (library {have[:16]}..., sources {want[:16]}...): "
+                                       "rebuild with `python -m news_recommendation_model_amd.build` (NRM_ALLOW_STALE_LIB=1 loads it anyway)")
         _lib = lib
     return _lib
+
+
+def provenance():
+    """{'library_sources_sha256', 'build_info'} of the loaded library."""
+    lib = load()
+    return {"library_sources_sha256": lib.nrm_source_digest().decode(), "build_info": lib.nrm_build_info().decode()}
 
 
 # Optional per-launch timing (bench.py): when a list is installed here every kernel-launching call is

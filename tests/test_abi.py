@@ -82,3 +82,13 @@ def test_gemm_tn_plans_of_the_c3_step_fill_one_round_of_wave_slots(lib):
         assert ns % 4 == 0 and 0.9 * 1024 * wps <= tiles * ns <= 1024 * wps, (ni, nj, R, ns)
     assert lib.nrm_gemm_tn_nsplit(64, 64, 3840, 0) == 30                  # small shapes: at least 128 rows per split
     assert lib.nrm_gemm_tn_nsplit(0, 64, 128, 0) == 0
+
+
+def test_library_says_which_sources_it_was_built_from(lib):
+    """Provenance: nrm_source_digest() of the loaded binary equals the digest of the kernel sources in the tree
+    (what profiles/ are stamped with and bench.py prints), and native.load refuses a library built from other sources."""
+    from news_recommendation_model_amd import build, native
+    prov = native.provenance()
+    assert prov["library_sources_sha256"] == build.sources_digest() and len(prov["library_sources_sha256"]) == 64
+    assert "gfx950" in prov["build_info"] and "built 20" in prov["build_info"]
+    assert build.library_digest() == build.sources_digest() and not build.needs_build()
