@@ -29,6 +29,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# this pool's host driver only supports dmabuf IPC: without it RCCL's buffer exchange between rank processes fails with
+# hipIpcGetMemHandle: invalid argument.  Set before anything initialises the GPU (also for ranks an external launcher started).
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
