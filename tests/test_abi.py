@@ -92,3 +92,19 @@ def test_library_says_which_sources_it_was_built_from(lib):
     assert prov["library_sources_sha256"] == build.sources_digest() and len(prov["library_sources_sha256"]) == 64
     assert "gfx950" in prov["build_info"] and "built 20" in prov["build_info"]
     assert build.library_digest() == build.sources_digest() and not build.needs_build()
+
+
+def test_loader_refuses_a_library_built_from_other_sources(lib, monkeypatch):
+    """native.load compares the binary's nrm_source_digest() with the kernel sources lying next to it: a tree whose csrc/ was
+    edited without a rebuild (here: the digest function is made to report other sources) is refused with a message that says how
+    to rebuild; NRM_ALLOW_STALE_LIB=1 and an explicit NRM_HOTPATH_LIB (variant builds of scripts/_diag) switch the check off."""
+    import pytest
+    from news_recommendation_model_amd import build, native
+    monkeypatch.setattr(native, "_lib", None)
+    monkeypatch.setattr(build, "sources_digest", lambda: "0" * 64)
+    monkeypatch.delenv("NRM_ALLOW_STALE_LIB", raising=False)
+    monkeypatch.delenv("NRM_HOTPATH_LIB", raising=False)
+    with pytest.raises(RuntimeError, match="built from other kernel sources"):
+        native.load()
+    monkeypatch.setenv("NRM_ALLOW_STALE_LIB", "1")
+    assert native.load().nrm_abi_version() == native.ABI_VERSION
