@@ -380,11 +380,14 @@ def _slab_reduce(ws, nsplit, nj, ldws, ni, out, out_is, out_js, out2=None, out2_
 
 
 # Weight-gradient stream.  dW = dY^T X feeds nothing but the optimizer, so inside ``deferred_slab_reductions()`` (i.e. under
-# trainer.train_step with FlatAdam, where nobody reads a weight gradient before collect_grads) the weight-gradient GEMMs of
-# big batches are issued on a side stream: they fill the gaps the dependent chain dX -> dX -> ... leaves on the chip
-# (C3: -0.9 ms per step).  flush_slab_reductions() joins the side stream before the reductions read the slabs.
-# NRM_WGRAD_STREAM=0|1 forces it off / on; by default it is on for operands of >= WGRAD_STREAM_MIN_ROWS rows.
-WGRAD_STREAM_MIN_ROWS = 20000
+# trainer.train_step with FlatAdam, where nobody reads a weight gradient before collect_grads) the weight-gradient GEMMs can be
+# issued on a side stream; flush_slab_reductions() joins it before the reductions read the slabs.  Round 3 measured that as worth
+# 0.1 ms at C3 and made it the default from 20 000 rows; with the round-4/5 kernels it is a LOSS where it applies: C3 eager 31.04 /
+# 31.04 / 31.18 ms without it against 31.63 / 31.93 / 31.76 with it (same box, alternating; after 40 warm-up steps 31.69 against
+# 32.11), the captured step the same either way (31.64 / 31.47), C5 116.4 / 116.5 (scripts/_diag/r5_eager_streams*.sh).  Two big
+# GEMMs sharing the chip take the sum of their times, and the cross-stream event waits are not free.  So it is OFF by default;
+# NRM_WGRAD_STREAM=1 turns it on (tests keep the path covered).
+WGRAD_STREAM_MIN_ROWS = 0
 _wgrad = {"streams": {}, "used": set()}
 
 
@@ -395,7 +398,7 @@ class _wgrad_stream:
         import os
         forced = os.environ.get("NRM_WGRAD_STREAM")
         self.inputs = inputs
-        self.on = _deferred["on"] and (forced == "1" or (forced is None and inputs[0].shape[0] >= WGRAD_STREAM_MIN_ROWS))
+        self.on = _deferred["on"] and forced == "1" and inputs[0].shape[0] >= WGRAD_STREAM_MIN_ROWS
 
     def __enter__(self):
         if not self.on:

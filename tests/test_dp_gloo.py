@@ -185,14 +185,14 @@ def _import_bench():
 def test_multi_rank_runs_step_eagerly_unless_graph_is_asked_for():
     """with a process group the DEFAULT launch mode is eager (an abort on ProcessGroupNCCL's watchdog thread
     during a capture never reaches an `except`, and the first multi-device contact of this code is the driver's scaling run);
-    the captured step with the RCCL all-reduce inside is opt-in.  One process without a group still probes both modes."""
+    the captured step with the RCCL all-reduce inside is opt-in.  One process without a group picks by step time ("rule")."""
     bench = _import_bench()
     mode, rule = bench.launch_policy(graph=False, eager=False, use_dist=True, backend="nccl")
     assert mode == "eager" and "opt-in" in rule and "--graph" in rule
     assert bench.launch_policy(True, False, True, "nccl")[0] == "graph"
     assert bench.launch_policy(False, True, True, "nccl")[0] == "eager"
     assert bench.launch_policy(False, False, True, "gloo")[0] == "eager"
-    assert bench.launch_policy(False, False, False, "nccl")[0] == "probe"
+    assert bench.launch_policy(False, False, False, "nccl")[0] == "rule"            # by step time; both modes probed after the timed region
     assert bench.launch_policy(True, False, False, "nccl")[0] == "graph"
     assert bench.launch_policy(False, True, False, "nccl")[0] == "eager"
     with pytest.raises(SystemExit):

@@ -187,14 +187,18 @@ def test_full_size_c3_train_step_big_batch_paths_match_their_small_batch_forms(l
         m.bn.load_state_dict(bn_before)                      # no optimizer step was taken: the model is as built again
         return out.detach().clone(), float(loss.detach()), g
 
-    # (a) the default paths of a big batch: counting sort, weight-gradient stream, two attention streams, deferred reductions
+    # (a) the paths of a big batch: counting sort, two attention streams, deferred reductions (defaults) + the weight-gradient stream
     for e in PATH_ENVS:
         monkeypatch.delenv(e, raising=False)
     big, bopt = fresh()
     ops._wgrad["streams"].clear()
     assert big.invariant_interest_model.uses_two_streams(B * T * H * D)
+    # (the weight-gradient stream is no default any more -- round 5 measured it as a loss at this size --; it is forced on for this
+    # first comparison so that the path stays covered at 30 720 / 51 200-row operands; the lock-step steps below run the real defaults)
+    monkeypatch.setenv("NRM_WGRAD_STREAM", "1")
     out_b, loss_b, g_b = grads_of_first_step(big, bopt, defer=True)
-    assert ops._wgrad["streams"], "the weight-gradient stream was not used at 30 720 rows"
+    assert ops._wgrad["streams"], "the weight-gradient stream was not used although forced on"
+    monkeypatch.delenv("NRM_WGRAD_STREAM")
     # (b) every one of them forced to its small-batch form
     monkeypatch.setenv("NRM_FE_SORT", "0")
     monkeypatch.setenv("NRM_WGRAD_STREAM", "0")
