@@ -505,6 +505,45 @@ def _pwattn_bwd_impl(ds, t, h, w1, w2, z, mma, need_dt, need_dh):
     return _attn_bwd_core(ds, t, h, w1, w2, z, mma, need_dt, need_dh)
 
 
+# Order of the two attentions' backward contractions when they run on two streams (round 5).  The label attention's chain
+# (dz -> (b,t) pass -> (b,h) pass) is followed on ITS stream by ~1.3 ms of atomic- / latency-bound work that depends on it (w1's
+# backward, the front-end scatter, the category sort); the text+image attention's dW_p-only pass depends on nothing but its own dz
+# and feeds nothing but the optimizer.  Issued as soon as its dz is ready it shares the matrix pipe with the (b,t) pass -- two
+# MFMA-bound kernels take the sum of their times -- and the tail then runs alone.  So a dW_p-only contraction waits for the end of a
+# full chain that was enqueued on ANOTHER stream earlier in the same step: it then overlaps the tail instead (C3 eager: DESIGN.md
+# section 4f).  trainer.train_step opens a step (begin_step); NRM_DW_LAST=0 switches the wait off.
+_chain = {"token": 0, "end": None}
+
+
+def begin_step():
+    _chain["token"] += 1
+    _chain["end"] = None
+
+
+def _note_chain_end():
+    ev = torch.cuda.Event()
+    ev.record()
+    _chain["end"] = (_chain["token"], ev, torch.cuda.current_stream(), torch.cuda.is_current_stream_capturing())
+
+
+# Measured (same box, alternating, eager): C3 (614 M z elements) 30.98 / 31.06 / 31.14 ms with the wait against 31.24 / 31.32 / 31.10
+# without, 31.47 against 31.74 after 40 warm-up steps, captured step 31.33 against 31.47; C5 (1.6 G) 117.9 against 116.6 -- its tail is
+# 2 % of a contraction, there is nothing to hide; C2 and smaller: their kernels do not fill the chip, side by side is the gain there.
+DW_LAST_MIN_ELEMS, DW_LAST_MAX_ELEMS = 200_000_000, 1_000_000_000
+
+
+def _wait_for_foreign_chain(z_elems):
+    import os
+    end = _chain["end"]
+    forced = os.environ.get("NRM_DW_LAST")
+    if end is None or forced == "0" or (forced != "1" and not (DW_LAST_MIN_ELEMS <= z_elems <= DW_LAST_MAX_ELEMS)):
+        return
+    token, ev, stream, capturing = end
+    cur = torch.cuda.current_stream()
+    if token == _chain["token"] and stream != cur and capturing == torch.cuda.is_current_stream_capturing():
+        cur.wait_event(ev)
+
+
 def _attn_bwd_core(ds, t, h, w1, w2, z, mma, need_dt=True, need_dh=True, acc=None):
     """``need_dt`` / ``need_dh``: whether the target / history rows want a gradient.  The text+image attention of the model reads
     raw input columns (reference user_invariant_interest_model.py:63-64,78: no parameter upstream), so autograd asks for neither
@@ -572,8 +611,12 @@ def _attn_bwd_core(ds, t, h, w1, w2, z, mma, need_dt=True, need_dh=True, acc=Non
             native.call("nrm_pwattn_bwd_rw_dtdh", native.ptr(dz), native.ptr(t), native.ptr(h), native.ptr(img), native.ptr(dt_),
                         native.ptr(dh_), B, T, H, D, mma, st, tag="pwattn_bwd_rw_dtdh")
         _count_flops("contraction", 2.0 * B * T * H * D * D)
+        if not (need_dt or need_dh):
+            _wait_for_foreign_chain(B * T * H * D)
         native.call("nrm_pwattn_bwd_contract", native.ptr(dz), native.ptr(t), native.ptr(h), native.ptr(wp), 4 * D, None, None,
                     native.ptr(wsp), B, T, H, D, 4, mma, DZ_HL4, st, tag="pwattn_bwd_e_bt")
+        if need_dt or need_dh:
+            _note_chain_end()
     else:
         # two launches: (b,t)-grouped -> dt + dW_p slabs, (b,h)-grouped -> dh (issued separately so that
         # bench.py can time each kernel with its own event pair); the second one only when the history wants a gradient
@@ -582,9 +625,13 @@ def _attn_bwd_core(ds, t, h, w1, w2, z, mma, need_dt=True, need_dh=True, acc=Non
             if passes == 2 and not need_dh:
                 continue
             _count_flops("contraction", 2.0 * B * T * H * D * D)
+            if not (need_dt or need_dh):
+                _wait_for_foreign_chain(B * T * H * D)     # the dW_p-only pass: behind the other attention's chain (see _chain)
             native.call("nrm_pwattn_bwd_contract", native.ptr(dz), native.ptr(t), native.ptr(h),
                         native.ptr(wp), 4 * D, native.ptr(dt) if need_dt else None, native.ptr(dh) if need_dh else None,
                         native.ptr(wsp), B, T, H, D, passes, mma, DZ_F32, st, tag=tag)
+        if need_dt or need_dh:
+            _note_chain_end()
     _slab_reduce(wsp, nsplit, D, D, D, dw1[:, 3 * D:], 4 * D, 1, target=w1_arg)    # slabs hold dW_p^T: ws[s][d][k] -> dw1[k, 3D + d]
     return dt, dh, dw1, db1, acc
 

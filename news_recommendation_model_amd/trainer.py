@@ -305,6 +305,7 @@ def train_step(model, optimizer, batch, reducer: FlatGradReducer | None = None, 
     loss = model.loss(batch["user_id"], out, batch["label"], alpha)
     if isinstance(optimizer, FlatAdam):
         from . import ops
+        ops.begin_step()                              # (stream ordering of the two attentions' backward contractions: ops._chain)
         # nobody reads a weight gradient between backward() and collect_grads(): the step's slab reductions (one per weight
         # gradient) are recorded during backward and run as ONE launch when FlatAdam gathers the gradients.  A gradient that
         # exists already would be accumulated into before its reduction ran: then (and on request) reductions run at once.

@@ -658,13 +658,18 @@ def test_flat_adam_collects_every_gradient_with_one_launch(lib):
     assert torch.equal(opt.grad_view(0), grads[0])
 
 
+@pytest.mark.parametrize("dw_last", ["0", "1"])
 @pytest.mark.parametrize("graphed", [False, True])
-def test_two_stream_attention_branches_match_one_stream(lib, monkeypatch, graphed):
+def test_two_stream_attention_branches_match_one_stream(lib, monkeypatch, graphed, dw_last):
     """modules.UserInvariantInterestModel.forward issues its second attention (and pool) on a side stream for small
     shapes: eager and captured into a HIP graph, forward, every gradient and three optimizer steps must land where the
-    one-stream step lands (same kernels; only the order of float atomics can differ)."""
+    one-stream step lands (same kernels; only the order of float atomics can differ).  ``dw_last`` (round 5): with and without
+    the text+image attention's dW_p-only pass waiting for the label attention's chain on the other stream (ops._chain; by
+    default only at C3-like sizes, forced here) -- an event recorded on one stream and waited for on the other, also inside a
+    capture."""
     from news_recommendation_model_amd import trainer
     monkeypatch.delenv("NRM_BRANCH_STREAMS", raising=False)
+    monkeypatch.setenv("NRM_DW_LAST", dw_last)
     case, one, tb, batch, fx = _model_and_batch("tiny_train")
     two = _model_and_batch("tiny_train")[1]
     one.train(); two.train()
