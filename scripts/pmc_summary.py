@@ -70,7 +70,7 @@ def pick(prefix):
     return max(c, key=lambda k: (out[k].get("SQ_WAVE_CYCLES", 0.0), out[k].get("FETCH_SIZE", 0.0))) if c else None
 
 
-walk = pick("pwattn_fwd_walk_kernel")
+walk = pick("pwattn_fwd_walk_")            # the bf16 walk or (round 5) the fp32 walk of D = 64
 fwd = walk if walk else pick("pwattn_fwd_rw_kernel") if (pick("pwattn_fwd_rw_kernel") and out[pick("pwattn_fwd_rw_kernel")].get("SQ_WAVE_CYCLES", 0) >
                                       out.get(pick("pwattn_fwd_kernel") or "", {}).get("SQ_WAVE_CYCLES", 0)) else pick("pwattn_fwd_kernel")
 e_kernels = sorted((k for k in out if k.startswith("bwd_e_kernel")), key=lambda k: -out[k].get("SQ_WAVE_CYCLES", 0.0))
