@@ -737,7 +737,9 @@ def main():
                 t_b = time_steps(eager_step if args.graph else graph_step, PROBE)
                 t_graph, t_eager = (t_a, t_b) if args.graph else (t_b, t_a)
                 probe.update(steps=PROBE, t_eager_ms=round(t_eager * 1e3, 4), t_graph_ms=round(t_graph * 1e3, 4),
-                             when="after the timed region (the timed mode first)")
+                             when="after the timed region (the timed mode first)",
+                             note="on big shapes the chip runs ~2 % slower once it has been under load for ~1.5 s (DESIGN.md 4f): these two "
+                                  "figures are from that state, ms_per_step from the contract's W warm-up + K timed steps")
             else:
                 probe.update(steps=0, when=f"capture failed: {capture_error}")
             if not args.graph:
