@@ -253,11 +253,11 @@ def launch_policy(graph, eager, use_dist, backend):
     """Launch mode of the timed region -> ("graph" | "eager" | "probe", rule).
 
     One process, no process group ("rule"): hipGraph replay when an eager step takes < 10 ms (the small shapes are launch-bound:
-    1.3-1.9 ms replayed against 3-4 ms eager), eager stepping above (C3: with real streams the two attention branches overlap, which
-    hipGraph's four execution queues serialise -- round 5: eager 31.0-31.2 / 31.7 ms cool / after 1.5 s of load, replay 31.3-31.6 /
-    31.9; C5: 116 against 120 ms).  Both modes are still timed over --probe-steps steps each, but AFTER the timed region (round 4 did
-    it before: 20 probe steps and four captures put the chip under load for 1.5 s before the contract's W warm-up steps, and every
-    mode then runs ~2 % slower -- DESIGN.md section 5), and reported in launch_probe.
+    1.3-1.9 ms replayed against 3-4 ms eager), eager stepping above -- what a multi-rank run does; at C3 the two modes are equal
+    once both are timed in the same state of the chip (round 5: 30.96 eager / 30.89 replayed cool, 31.65-31.87 / 31.66-31.70 after
+    1.5 s of load), C5 116 against 120 ms.  Both modes are still timed over --probe-steps steps each, but AFTER the timed region (round
+    4 did it before: 20 probe steps and four captures put the chip under load for 1.5 s before the contract's W warm-up steps, and
+    every mode then runs ~2 % slower -- DESIGN.md section 4f), and reported in launch_probe.
     With a process group (N > 1, or the one-rank RCCL rehearsal) the DEFAULT IS EAGER: a captured step
     contains the in-stream RCCL all-reduce, ProcessGroupNCCL's watchdog thread polls events while the main thread captures, and
     an abort on that thread never reaches an `except` here -- the first multi-device contact of this code is the driver's
