@@ -463,6 +463,8 @@ def _pwattn_fwd_impl(t, h, w1, b1, w2, b2, save_z, mma):
     """s[b,t,h] = fc2(GELU(fc1(cat[h, t, t-h, t*h]))) with fc1 = [W_h|W_t|W_d|W_p] re-associated as
     z = h(W_h-W_d)^T + b1 + t(W_t+W_d)^T + sum_d W_p[:,d] t_d h_d  (SURVEY.md §8 a7)."""
     _require_gpu(t, h, w1, b1, w2, b2)
+    if save_z:
+        _chain["end"] = None               # a training forward: whatever an earlier backward left there is stale (see _chain below)
     B, T, D = t.shape
     H = h.shape[1]
     if h.shape[0] != B or h.shape[2] != D or tuple(w1.shape) != (D, 4 * D) or D % 4:
@@ -511,7 +513,8 @@ def _pwattn_bwd_impl(ds, t, h, w1, w2, z, mma, need_dt, need_dh):
 # and feeds nothing but the optimizer.  Issued as soon as its dz is ready it shares the matrix pipe with the (b,t) pass -- two
 # MFMA-bound kernels take the sum of their times -- and the tail then runs alone.  So a dW_p-only contraction waits for the end of a
 # full chain that was enqueued on ANOTHER stream earlier in the same step: it then overlaps the tail instead (C3 eager: DESIGN.md
-# section 4f).  trainer.train_step opens a step (begin_step); NRM_DW_LAST=0 switches the wait off.
+# section 4f).  A chain's end is only ever waited for inside the backward pass it belongs to: every training forward clears it (and
+# trainer.train_step opens a step, begin_step); NRM_DW_LAST=0 switches the wait off.
 _chain = {"token": 0, "end": None}
 
 
