@@ -208,15 +208,17 @@ def test_heartbeat_fires_on_no_progress_only_and_names_the_phase():
     import time
     bench = _import_bench()
     codes, log = [], io.StringIO()
-    hb = bench.Heartbeat(0.4, rank=3, poll=0.05, out=log, _exit=codes.append)
+    hb = bench.Heartbeat(1.0, rank=3, poll=0.05, out=log, _exit=codes.append)      # (generous against a loaded test machine)
     t0 = time.monotonic()
-    while time.monotonic() - t0 < 1.2:                  # three deadlines' worth of healthy progress
+    while time.monotonic() - t0 < 3.0:                  # three deadlines' worth of healthy progress
         hb.beat("timed steps")
         time.sleep(0.05)
     assert codes == [] and hb.beats > 10
     hb.beat("final barrier")
-    time.sleep(0.9)                                      # ... and now a hang
-    assert codes == [124]
+    t1 = time.monotonic()
+    while not codes and time.monotonic() - t1 < 10.0:    # ... and now a hang: it fires once the deadline has passed
+        time.sleep(0.05)
+    assert codes == [124] and time.monotonic() - t1 >= 0.9
     text = log.getvalue()
     assert "rank 3" in text and "'final barrier'" in text and "without progress" in text
     # a stopped heartbeat never fires (the final print of rank 0 may take long: fwd_auc_parity, cpu_baseline)
