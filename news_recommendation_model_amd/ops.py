@@ -651,9 +651,11 @@ pwattn_bwd = _op("pwattn_bwd", "(Tensor ds, Tensor t, Tensor h, Tensor fc1_weigh
                  "bool need_dt, bool need_dh) -> (Tensor, Tensor, Tensor, Tensor, Tensor)", _pwattn_bwd_impl, _pwattn_bwd_fake)
 
 
-# The backward overwrites the saved [B,T,H,D] pre-activation in place (2.46 GB at C3: no second copy), so by default a graph
-# can be walked once.  set_retain_attention_graph(True) restores the reference's behaviour (autograd.grad(..., retain_graph=True),
-# a second backward): every backward then works on a COPY of z -- one extra [B,T,H,D] buffer and one copy per backward.
+# The backward overwrites the saved [B,T,H,D] pre-activation in place (2.46 GB at C3: no second copy).  A SECOND backward through the
+# same graph (autograd.grad(..., retain_graph=True), which the reference's autograd allows: models/attention_model.py:92) therefore
+# finds the buffer spent -- and RECOMPUTES the pre-activation from the saved inputs with one extra forward kernel (round 5; rounds
+# 1-4 raised).  The usual single backward pays nothing for this.  set_retain_attention_graph(True) selects the other trade: every
+# backward works on a COPY of z (one extra [B,T,H,D] buffer and one copy per backward, no recomputation).
 _retain_attention_graph = False
 
 
@@ -663,14 +665,15 @@ def set_retain_attention_graph(on=True):
     return prev
 
 
-def _consume_z(ctx, z):
-    """The dz buffer of this backward: z itself (then the graph is spent) or, with set_retain_attention_graph, a copy."""
+def _consume_z(ctx, z, t, h, w1, b1, w2):
+    """The dz buffer of this backward: z itself on the first walk of the graph; a copy with set_retain_attention_graph; on a later
+    walk (the buffer now holds the first walk's dz) the pre-activation recomputed from the saved inputs."""
     if _retain_attention_graph:
         return z.detach().clone()
     if ctx.consumed:
-        raise RuntimeError("pointwise attention: backward through this graph a second time is not supported "
-                           "(the saved pre-activation buffer was consumed by the first backward); re-run the forward "
-                           "instead of retain_graph=True, or call ops.set_retain_attention_graph(True) first")
+        with torch.no_grad():
+            b2 = torch.zeros(1, dtype=torch.float32, device=t.device)            # (does not enter z)
+            return _pwattn_fwd_impl(t.detach(), h.detach(), w1.detach(), b1.detach(), w2.detach(), b2, True, ctx.mma)[1]
     ctx.consumed = True
     return z.detach()
 
@@ -684,7 +687,7 @@ def _pwattn_setup(ctx, inputs, output):
     ctx.consumed = False
     ctx.w2_shape, ctx.b2_shape = tuple(w2.shape), tuple(b2.shape)
     if save_z:
-        ctx.save_for_backward(t, h, w1, w2, z)
+        ctx.save_for_backward(t, h, w1, w2, z, b1)
 
 
 def _pwattn_backward(ctx, ds, _dz):
@@ -693,9 +696,9 @@ def _pwattn_backward(ctx, ds, _dz):
     if not ctx.save_z:
         raise RuntimeError("pointwise attention: the forward ran with save_z=False (no-grad / inference call); there "
                            "is nothing to differentiate through")
-    t, h, w1, w2, z = ctx.saved_tensors
+    t, h, w1, w2, z, b1 = ctx.saved_tensors
     need = ctx.needs_input_grad
-    dt, dh, dw1, db1, dw2b2 = pwattn_bwd(ds, t, h, w1, w2, _consume_z(ctx, z), ctx.mma, bool(need[0]), bool(need[1]))
+    dt, dh, dw1, db1, dw2b2 = pwattn_bwd(ds, t, h, w1, w2, _consume_z(ctx, z, t, h, w1, b1, w2), ctx.mma, bool(need[0]), bool(need[1]))
     D = t.shape[2]
     return ((dt if need[0] else None), (dh if need[1] else None), dw1, db1, dw2b2[:D].reshape(ctx.w2_shape),
             dw2b2[D:D + 1].reshape(ctx.b2_shape), None, None)
@@ -1365,7 +1368,7 @@ def _attend_pool_setup(ctx, inputs, output):
     ctx.w2_shape, ctx.b2_shape = tuple(w2.shape), tuple(b2.shape)
     ctx.mark_non_differentiable(s, z)
     if save_z:
-        ctx.save_for_backward(t, h, w1, w2, s, z)
+        ctx.save_for_backward(t, h, w1, w2, s, z, b1)
 
 
 def _attend_pool_backward(ctx, g, _ds, _dz):
@@ -1374,9 +1377,9 @@ def _attend_pool_backward(ctx, g, _ds, _dz):
     if not ctx.save_z:
         raise RuntimeError("pointwise attention: the forward ran with save_z=False (no-grad / inference call); there "
                            "is nothing to differentiate through")
-    t, h, w1, w2, s, z = ctx.saved_tensors
+    t, h, w1, w2, s, z, b1 = ctx.saved_tensors
     need = ctx.needs_input_grad
-    dt, dh, dw1, db1, dw2b2 = attend_pool_bwd(g, t, h, w1, w2, s, _consume_z(ctx, z), ctx.mma, bool(need[0]), bool(need[1]))
+    dt, dh, dw1, db1, dw2b2 = attend_pool_bwd(g, t, h, w1, w2, s, _consume_z(ctx, z, t, h, w1, b1, w2), ctx.mma, bool(need[0]), bool(need[1]))
     D = t.shape[2]
     return ((dt if need[0] else None), (dh if need[1] else None), dw1, db1, dw2b2[:D].reshape(ctx.w2_shape),
             dw2b2[D:D + 1].reshape(ctx.b2_shape), None, None)
