@@ -249,7 +249,9 @@ def test_full_size_c3_train_step_big_batch_paths_match_their_small_batch_forms(l
 
     def compare(other, oopt, g_flat, delta, what):
         du, dm, dv, certain = _one_step_bounds(sopt, g_flat + sopt.weight_decay * before["p"], delta)
-        tiny = EPS32 * before["p"].abs() + 1e-12
+        # one rounding of the new weight itself: an ulp of the larger of the weight before and after its step (an entry of 2e-5
+        # that takes a step of lr lands near 3e-4, where an ulp is 16x that of the old value -- seen once in 20 runs, round 5)
+        tiny = EPS32 * torch.maximum(before["p"].abs(), sopt.flat_param.abs()) + 1e-12
         for got, ref, bound, name in ((oopt.flat_param, sopt.flat_param, du, "weights"), (oopt.exp_avg, sopt.exp_avg, dm, "exp_avg"),
                                       (oopt.exp_avg_sq, sopt.exp_avg_sq, dv, "exp_avg_sq")):
             # (+ one rounding of the result itself: two fma results whose exact values are closer than an ulp can still differ by one)
