@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define NRM_ABI_VERSION 5
+#define NRM_ABI_VERSION 6
 #define NRM_OK 0
 #define NRM_EINVAL (-1)   /* bad shape / alignment / null pointer */
 #define NRM_ELAUNCH (-2)  /* HIP launch error */
@@ -100,6 +100,18 @@ long nrm_pwattn_bwd_rw_packed_floats(int D, int mma);
 int nrm_pwattn_bwd_rw_pack(const float* fc1_weight, int ld, int D, int mma, float* packed, nrm_stream_t stream);
 int nrm_pwattn_bwd_rw_dtdh(const float* dz_hl4, const float* t, const float* h, const float* packed, float* dt, float* dh,
                            int B, int T, int H, int D, int mma, nrm_stream_t stream);
+
+/* backward, step 2 in the "dP walk" form (fp32, D % 4 == 0, H >= 16): the same dt / dh as nrm_pwattn_bwd_contract passes 1 + 2
+ * from ONE contraction dP = dz W_p with the forward's streaming skeleton (dz fp32, read once per 208-column chunk of d); the
+ * caller then takes dW_p from nrm_pwattn_bwd_contract with passes = 4.  Autograd of models/attention_model.py:81-92 w.r.t.
+ * target and history.  nrm_pwattn_bwd_dp_supported: 1 if (D, H) has this form;
+ * packed: nrm_pwattn_bwd_dp_packed_floats floats filled by nrm_pwattn_bwd_dp_pack from fc1_weight [D, 4D] (row stride ld).
+ * dt / dh are accumulated into (float atomics). */
+int nrm_pwattn_bwd_dp_supported(int D, int H);
+long nrm_pwattn_bwd_dp_packed_floats(int D, int H);
+int nrm_pwattn_bwd_dp_pack(const float* fc1_weight, int ld, int D, int H, float* packed, nrm_stream_t stream);
+int nrm_pwattn_bwd_dp_dtdh(const float* dz, const float* t, const float* h, const float* packed, float* dt, float* dh,
+                           int B, int T, int H, int D, nrm_stream_t stream);
 
 /* ---- dense layers: reference MLP.forward (models/attention_model.py:29-32: fc1 -> GELU -> fc2), the history
  *      projection w1 (models/user_invariant_interest_model.py:78) and the attention's side projections.

@@ -15,7 +15,7 @@ import tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnrm_hotpath.so")
-SOURCES = ["pwattn_fwd.hip", "pwattn_fwd_rw.hip", "pwattn_bwd.hip", "pwattn_bwd_rw.hip", "gemm.hip", "gemm_bf16.hip", "head.hip", "pool_loss.hip",
+SOURCES = ["pwattn_fwd.hip", "pwattn_fwd_rw.hip", "pwattn_bwd.hip", "pwattn_bwd_rw.hip", "pwattn_bwd_dp.hip", "gemm.hip", "gemm_bf16.hip", "head.hip", "pool_loss.hip",
            "frontend.hip", "capi.hip"]
 OBJDIR = os.path.join(HERE, "build")          # per-source objects (git-ignored): only changed sources are recompiled
 

@@ -139,6 +139,32 @@ int nrm_pwattn_bwd_rw_dtdh(const float* dz_hl4, const float* t, const float* h, 
     return check_hip(nrm::pwattn_bwd_rw_launch(p, mma, (hipStream_t)stream), "bwd_rw_dtdh");
 }
 
+int nrm_pwattn_bwd_dp_supported(int D, int H) { return nrm::pwattn_bwd_dp_plan(D, H).NT ? 1 : 0; }
+long nrm_pwattn_bwd_dp_packed_floats(int D, int H) { return nrm::pwattn_bwd_dp_packed_floats(D, H); }
+
+int nrm_pwattn_bwd_dp_pack(const float* fc1_weight, int ld, int D, int H, float* packed, nrm_stream_t stream) {
+    if (!fc1_weight || !packed) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dp_pack: null pointer");
+    if (D <= 0 || D % 4 || ld < 4 * D) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dp_pack: D=%d ld=%d (need D%%4==0, ld>=4D)", D, ld);
+    if (!nrm_pwattn_bwd_dp_supported(D, H)) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dp_pack: D=%d H=%d has no dP-walk backward", D, H);
+    return check_hip(nrm::pwattn_bwd_dp_pack_launch(fc1_weight + 3 * (long)D, ld, D, H, packed, (hipStream_t)stream), "bwd_dp_pack");
+}
+
+int nrm_pwattn_bwd_dp_dtdh(const float* dz, const float* t, const float* h, const float* packed, float* dt, float* dh,
+                           int B, int T, int H, int D, nrm_stream_t stream) {
+    if (int rc = check_dims("nrm_pwattn_bwd_dp_dtdh", B, T, H, D)) return rc;
+    if (!dz || !t || !h || !packed || !dt || !dh) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dp_dtdh: null pointer");
+    if (!nrm_pwattn_bwd_dp_supported(D, H)) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dp_dtdh: D=%d H=%d has no dP-walk backward (D %% 4 == 0, H >= 16)", D, H);
+    // a row block of 64 history rows spans at most 63 / H + 2 impressions, whose dz blocks one buffer descriptor must cover
+    if ((long)(63 / H + 2) * T * H * D * 4 >= (1L << 31)) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dp_dtdh: the dz blocks of one row block exceed 2^31 bytes");
+    if ((long)B * H * D * 4 >= (1L << 31) || (long)B * T * D * 4 >= (1L << 31)) return fail(NRM_EINVAL, "nrm_pwattn_bwd_dp_dtdh: t or h exceeds 2^31 bytes");
+    if (B == 0) return NRM_OK;
+    nrm::BwdDpParams p = {};
+    p.dz = dz; p.t = t; p.h = h; p.wimg = packed; p.dt = dt; p.dh = dh; p.B = B; p.T = T; p.H = H; p.D = D;
+    p.w_bytes = (unsigned)(nrm_pwattn_bwd_dp_packed_floats(D, H) * 4);
+    p.t_bytes = (unsigned)((long)B * T * D * 4); p.h_bytes = (unsigned)((long)B * H * D * 4);
+    return check_hip(nrm::pwattn_bwd_dp_launch(p, (hipStream_t)stream), "bwd_dp_dtdh");
+}
+
 int nrm_pwattn_bwd_nsplit(int B, int T, int H, int D, int mma) {
     if (B <= 0 || T <= 0 || H <= 0 || D <= 0) return 0;
     int tw1 = kBtWaves;

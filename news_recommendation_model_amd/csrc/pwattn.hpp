@@ -77,6 +77,26 @@ long pwattn_bwd_rw_packed_floats(int D, int mma);
 hipError_t pwattn_bwd_rw_pack_launch(const float* wp, int ldw, int D, int mma, float* packed, hipStream_t st);
 hipError_t pwattn_bwd_rw_launch(const BwdRwParams& p, int mma, hipStream_t st);
 
+// ---- backward of the bilinear term in fp32, dP walk form (pwattn_bwd_dp.hip): dt and dh from ONE contraction dP = dz W_p with the
+// forward's K-chunk-streaming skeleton; dW_p then comes from the (b,t) pass without its dt epilogue
+struct BwdDpParams {
+    const float* dz;     // [B*T*H, D] fp32
+    const float* t;      // [B*T, D]
+    const float* h;      // [B*H, D]
+    const float* wimg;   // packed by pwattn_bwd_dp_pack_launch
+    float* dt;           // [B*T, D]  +=
+    float* dh;           // [B*H, D]  +=
+    int B, T, H, D;
+    unsigned w_bytes, t_bytes, h_bytes;
+    int rows, kchunks, nchunks;   // of the plan (set by the launcher)
+    long steps;                   // (row blocks of 64) x N-chunks x T (set by the launcher)
+};
+struct BwdDpPlan { int NT, nchunks, rows, kchunks; };     // NT == 0: this (D, H) keeps the E-form
+BwdDpPlan pwattn_bwd_dp_plan(int D, int H);
+long pwattn_bwd_dp_packed_floats(int D, int H);
+hipError_t pwattn_bwd_dp_pack_launch(const float* wp, int ldw, int D, int H, float* packed, hipStream_t st);
+hipError_t pwattn_bwd_dp_launch(BwdDpParams p, hipStream_t st);
+
 // Non-zero when the translation unit was compiled with a timing-diagnostic override (scripts/_diag): such a library computes
 // WRONG results by construction; capi.hip ORs these into nrm_build_flags() and native.load refuses a non-zero value.
 int pwattn_fwd_diag_flags();        // pwattn_fwd.hip:     bit 0 NRM_DIAG_FWD, bit 1 XCD_REMAP off

@@ -11,7 +11,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NRM_HOTPATH_LIB") or os.path.join(_HERE, "libnrm_hotpath.so")   # override: diagnostic builds (scripts/_diag)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c_fp = ctypes.c_void_p      # device pointers travel as integers
 _c_i, _c_l = ctypes.c_int, ctypes.c_long
@@ -31,6 +31,10 @@ SIGNATURES = {
     "nrm_pwattn_bwd_rw_packed_floats": (_c_l, [_c_i, _c_i]),
     "nrm_pwattn_bwd_rw_pack": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp]),
     "nrm_pwattn_bwd_rw_dtdh": (_c_i, [_c_fp] * 6 + [_c_i] * 5 + [_c_fp]),
+    "nrm_pwattn_bwd_dp_supported": (_c_i, [_c_i, _c_i]),
+    "nrm_pwattn_bwd_dp_packed_floats": (_c_l, [_c_i, _c_i]),
+    "nrm_pwattn_bwd_dp_pack": (_c_i, [_c_fp, _c_i, _c_i, _c_i, _c_fp, _c_fp]),
+    "nrm_pwattn_bwd_dp_dtdh": (_c_i, [_c_fp] * 6 + [_c_i] * 4 + [_c_fp]),
     "nrm_pwattn_bwd_nsplit": (_c_i, [_c_i] * 5),
     "nrm_pwattn_bwd_contract": (_c_i, [_c_fp] * 4 + [_c_i] + [_c_fp] * 3 + [_c_i] * 7 + [_c_fp]),
     "nrm_gemm_packed_floats": (_c_l, [_c_i, _c_i, _c_i]),

@@ -547,6 +547,19 @@ def _wait_for_foreign_chain(z_elems):
         cur.wait_event(ev)
 
 
+# fp32 backward of the bilinear term: the dP walk (one contraction for dt AND dh + the dW_p-only pass) instead of the two E-form
+# passes.  NRM_BWD_DP=1 forces it wherever the library has it (D % 4 == 0, H >= 16), =0 never; default: by size (DP_MIN_ELEMS).
+DP_MIN_ELEMS = 1 << 62
+
+
+def _use_dp_walk(lib, B, T, H, D, mma):
+    import os
+    forced = os.environ.get("NRM_BWD_DP")
+    if mma != MMA_F32 or forced == "0" or not lib.nrm_pwattn_bwd_dp_supported(D, H):
+        return False
+    return forced == "1" or B * T * H * D >= DP_MIN_ELEMS
+
+
 def _attn_bwd_core(ds, t, h, w1, w2, z, mma, need_dt=True, need_dh=True, acc=None):
     """``need_dt`` / ``need_dh``: whether the target / history rows want a gradient.  The text+image attention of the model reads
     raw input columns (reference user_invariant_interest_model.py:63-64,78: no parameter upstream), so autograd asks for neither
@@ -620,6 +633,18 @@ def _attn_bwd_core(ds, t, h, w1, w2, z, mma, need_dt=True, need_dh=True, acc=Non
                     native.ptr(wsp), B, T, H, D, 4, mma, DZ_HL4, st, tag="pwattn_bwd_e_bt")
         if need_dt or need_dh:
             _note_chain_end()
+    elif need_dt and need_dh and _use_dp_walk(lib, B, T, H, D, mma):
+        # fp32, both row gradients wanted: dt and dh from ONE contraction dP = dz W_p (csrc/pwattn_bwd_dp.hip: the forward's
+        # streaming skeleton walking the candidates), then the (b,t)-grouped pass without its dt epilogue for the dW_p slabs
+        img = torch.empty(lib.nrm_pwattn_bwd_dp_packed_floats(D, H), dtype=torch.float32, device=dev)
+        native.call("nrm_pwattn_bwd_dp_pack", native.ptr(w1), 4 * D, D, H, native.ptr(img), st)
+        _count_flops("contraction", 2.0 * B * T * H * D * D)
+        native.call("nrm_pwattn_bwd_dp_dtdh", native.ptr(dz), native.ptr(t), native.ptr(h), native.ptr(img), native.ptr(dt),
+                    native.ptr(dh), B, T, H, D, st, tag="pwattn_bwd_dp_dtdh")
+        _count_flops("contraction", 2.0 * B * T * H * D * D)
+        native.call("nrm_pwattn_bwd_contract", native.ptr(dz), native.ptr(t), native.ptr(h), native.ptr(wp), 4 * D, None, None,
+                    native.ptr(wsp), B, T, H, D, 4, mma, DZ_F32, st, tag="pwattn_bwd_e_dw")
+        _note_chain_end()
     else:
         # two launches: (b,t)-grouped -> dt + dW_p slabs, (b,h)-grouped -> dh (issued separately so that
         # bench.py can time each kernel with its own event pair); the second one only when the history wants a gradient

@@ -79,7 +79,7 @@ dw = next((k for k in e_kernels if k.endswith(", 0, false, false>")), None)
 bt = pick("bwd_dw_r32_kernel") or next((k for k in e_kernels if k != dw and (", true, true" in k or ", true, false" in k)), None)   # dW_p-only form (bf16), or the WITH_DW instantiation = the (b,t) pass
 bh = pick("bwd_e_pipe_kernel") or next((k for k in e_kernels if k not in (bt, dw)), None)
 names = {"nrm_pwattn_fwd": fwd, "nrm_pwattn_bwd_dz": pick("bwd_dz_"), "pwattn_bwd_e_bt": bt, "pwattn_bwd_e_dw": dw, "pwattn_bwd_e_bh": bh,
-         "pwattn_bwd_rw_dtdh": pick("bwd_dp_rw_kernel")}
+         "pwattn_bwd_rw_dtdh": pick("bwd_dp_rw_kernel"), "pwattn_bwd_dp_dtdh": pick("bwd_dp_walk_kernel")}
 traffic = dict(stamp)
 traffic["_note"] = ("rocprofv3 PMC (separate passes, scripts/collect_profiles.sh), mean per full-size launch. FETCH_SIZE/WRITE_SIZE are KB. "
                     "Per MI355X_MICROARCH.md FETCH_SIZE under-reports wide (16 B/lane) coalesced streaming reads by 2x on gfx950: "

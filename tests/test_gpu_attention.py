@@ -172,6 +172,45 @@ def test_full_row_dz_pass_matches_oracle_and_slab_form(lib, monkeypatch, mma, B,
         assert rel_err(got[k], slab[k]) < 2e-5, (k, rel_err(got[k], slab[k]))
 
 
+# dP walk form of the fp32 backward (csrc/pwattn_bwd_dp.hip, round 5: dt and dh from ONE contraction dP = dz W_p, dW_p from the (b,t)
+# pass without its epilogue), forced on (NRM_BWD_DP=1) against the oracle and against the E-form (NRM_BWD_DP=0): histories that are not
+# a multiple of 16 (a wave's 16 flattened rows reach into the next impression), row counts that are not a multiple of 64, H = 16,
+# every N-chunk plan (4 / 8 / 12 / 13 tiles; one, two and four chunks), D that is not a multiple of 16, one candidate, more
+# workgroups than steps / 4 (NRM_DP_GRID) and a single workgroup walking everything
+DP_SHAPES = [(2, 30, 50, 400), (3, 7, 19, 72), (2, 15, 200, 64), (1, 64, 128, 768), (7, 5, 37, 100), (2, 9, 21, 320), (1, 5, 17, 388),
+             (1, 4, 16, 420), (5, 1, 16, 64), (9, 3, 23, 132), (2, 11, 16, 400), (33, 2, 17, 208), (4, 6, 50, 256), (1, 3, 300, 64)]
+
+
+@pytest.mark.parametrize("B,T,H,D", DP_SHAPES)
+def test_dp_walk_backward_matches_oracle_and_e_form(lib, monkeypatch, B, T, H, D):
+    assert lib.nrm_pwattn_bwd_dp_supported(D, H) == 1
+    rng = np.random.default_rng(B * 1000 + T * 100 + H * 10 + D + 5)
+    w = _weights(rng, D)
+    tgt = rng.standard_normal((B, T, D)).astype(np.float32)
+    his = rng.standard_normal((B, H, D)).astype(np.float32)
+    gs = rng.standard_normal((B, T, H)).astype(np.float32)
+    monkeypatch.setenv("NRM_BWD_DP", "0")
+    _, eform, _, _ = _run_both(w, tgt, his, gs)
+    monkeypatch.setenv("NRM_BWD_DP", "1")
+    for grid in (None, "1", "7"):
+        if grid is None:
+            monkeypatch.delenv("NRM_DP_GRID", raising=False)
+        else:
+            monkeypatch.setenv("NRM_DP_GRID", grid)
+        s, got, s_ref, ref = _run_both(w, tgt, his, gs)
+        assert rel_err(s, s_ref) < FWD_TOL
+        for k in ref:
+            assert rel_err(got[k], ref[k]) < GRAD_TOL, (grid, k, rel_err(got[k], ref[k]))
+            # the same products in another summation order
+            assert rel_err(got[k], eform[k]) < 2e-5, (grid, k, rel_err(got[k], eform[k]))
+
+
+def test_dp_walk_is_not_offered_where_it_cannot_run(lib):
+    assert lib.nrm_pwattn_bwd_dp_supported(400, 15) == 0              # a wave's 16 rows could span three impressions
+    assert lib.nrm_pwattn_bwd_dp_supported(66, 50) == 0               # rows that are not 16-byte multiples
+    assert lib.nrm_pwattn_bwd_dp_packed_floats(400, 50) == 25 * 2 * 13 * 16 * 16
+
+
 @pytest.mark.parametrize("mma", ["f32", "bf16x3"])
 @pytest.mark.parametrize("B,T,H,D", [(32, 6, 16, 400), (33, 5, 50, 256), (40, 4, 24, 64)])
 def test_default_dispatch_at_batch_32_matches_oracle(lib, monkeypatch, mma, B, T, H, D):
