@@ -52,7 +52,7 @@ extern "C" {
 
 int nrm_abi_version(void) { return NRM_ABI_VERSION; }
 int nrm_build_flags(void) { return nrm::pwattn_fwd_diag_flags() | nrm::pwattn_fwd_rw_diag_flags() | nrm::pwattn_bwd_diag_flags() |
-                                    nrm::pwattn_bwd_rw_diag_flags() | nrm::gemm_bf16_diag_flags() | nrm::gemm_diag_flags()
+                                    nrm::pwattn_bwd_rw_diag_flags() | nrm::pwattn_bwd_dp_diag_flags() | nrm::gemm_bf16_diag_flags() | nrm::gemm_diag_flags()
 #if defined(NRM_STORE_GUARD) && NRM_STORE_GUARD != 2
                                     | 0x200                            // 16-byte stores without (or with a weaker) hazard guard: common.hpp
 #endif

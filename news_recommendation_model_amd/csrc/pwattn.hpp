@@ -102,6 +102,7 @@ hipError_t pwattn_bwd_dp_launch(BwdDpParams p, hipStream_t st);
 int pwattn_fwd_diag_flags();        // pwattn_fwd.hip:     bit 0 NRM_DIAG_FWD, bit 1 XCD_REMAP off
 int pwattn_fwd_rw_diag_flags();     // pwattn_fwd_rw.hip:  bit 2 NRM_DIAG_RW
 int pwattn_bwd_rw_diag_flags();     // pwattn_bwd_rw.hip:  bit 9 NRM_DIAG_BRW
+int pwattn_bwd_dp_diag_flags();     // pwattn_bwd_dp.hip:  bit 10 NRM_DIAG_DP
 int pwattn_bwd_diag_flags();        // pwattn_bwd.hip:     bits 3.. NRM_EPI_AHEAD off, GELU_AT_LOAD, NOEPI, NOATOM, NOLOAD, NRM_PIPE_SGB off
 
 }  // namespace nrm

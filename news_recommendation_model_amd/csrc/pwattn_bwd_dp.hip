@@ -20,10 +20,18 @@
 //   * d-column layout inside an N-chunk of 16 NT columns: tile it < 4 (NT / 4) of 64-column group g = it >> 2 holds
 //     d = 64 g + 4 c16 + (it & 3) (one 16-byte load of a t / h row feeds four tiles, and one dword per lane of the four q
 //     rows forms a contiguous 256-byte segment); the NT % 4 tiles behind the last whole group hold d = 64 (NT / 4) + 16 i + c16;
-//   * work = (row block, N-chunk, candidate) steps in that order, cut into EQUAL contiguous ranges over a grid of one round of
-//     workgroups (3 per CU): no tail round, and the LDS ring runs on across steps (the first chunk of step s + 1 is requested
-//     under the last chunk of step s).
+//   * work = (row block, N-chunk, candidate) steps in that order, cut into EQUAL contiguous ranges over a grid of four rounds of
+//     workgroups (3 per CU): the tail is a sixteenth of a range, and the LDS ring runs on across steps (the first chunk of
+//     step s + 1 is requested under the last chunk of step s).
 #include <cstdlib>
+// timing diagnostics only (results are WRONG with any bit set; reported by nrm_build_flags): bit 0 no dz DMA after a step's first
+// chunk, bit 1 no epilogue, bit 2 no W DMA after a step's first chunk
+#ifndef NRM_DIAG_DP
+#define NRM_DIAG_DP 0
+#endif
+#ifndef DP_WPE
+#define DP_WPE 3          // tuning: launch bound, waves per SIMD
+#endif
 #include "common.hpp"
 #include "pwattn.hpp"
 
@@ -86,7 +94,7 @@ hipError_t pwattn_bwd_dp_pack_launch(const float* wp, int ldw, int D, int H, flo
 }
 
 template <int NT>
-__global__ __launch_bounds__(256, 3) void bwd_dp_walk_kernel(const BwdDpParams p) {
+__global__ __launch_bounds__(256, DP_WPE) void bwd_dp_walk_kernel(const BwdDpParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = 4, BM = 64;
     constexpr int WROWS = NT * 16;
@@ -206,9 +214,11 @@ __global__ __launch_bounds__(256, 3) void bwd_dp_walk_kernel(const BwdDpParams p
     // K-chunk c of step (t) -> ring stage `buf`: every wave its own 16 dz rows (one 1-KiB piece) and every 4th piece of W
     auto dma_chunk = [&](int c, int t, float* buf) {
         const int wbase = (c * p.rows + nc * WROWS) * 64;                 // bytes, uniform
+        if (!((NRM_DIAG_DP & 4) && c > 0))
         for (int pc = wave; pc < NT; pc += NW)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(buf + pc * 256),
                                                      16, lane * 16, wbase + pc * 1024, 0, 0);
+        if (!((NRM_DIAG_DP & 1) && c > 0))
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_z, (__attribute__((address_space(3))) void*)(buf + (WROWS + wave * 16) * 16),
                                                  16, voff_z, t * zstep + c * 64, 0, 0);
     };
@@ -248,6 +258,11 @@ __global__ __launch_bounds__(256, 3) void bwd_dp_walk_kernel(const BwdDpParams p
         }
 
         // ---- epilogue of the step: dh (lane-local) and dt (both segments; reduce over the 16 rows, one atomic row segment per group)
+        if (NRM_DIAG_DP & 2) {                                            // keep the accumulators alive, nothing else
+#pragma unroll
+            for (int it = 0; it < NT; ++it) { asm volatile("" :: "v"(acc[it])); dhacc[it] += acc[it]; }
+            continue;
+        }
         const int soff_h = colbase * 4;
         const int soff_t = (t * D + colbase) * 4;
         float* dtA = p.dt + (rowA + t) * D + colbase;
@@ -336,6 +351,8 @@ __global__ __launch_bounds__(256, 3) void bwd_dp_walk_kernel(const BwdDpParams p
 #endif
 }
 
+int pwattn_bwd_dp_diag_flags() { return NRM_DIAG_DP ? 1024 : 0; }
+
 static int dp_cus() {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
@@ -344,8 +361,9 @@ static int dp_cus() {
 
 template <int NT>
 static hipError_t launch_dp(BwdDpParams p, hipStream_t st) {
-    // one round of workgroups at three per CU; never fewer than 4 steps per workgroup (a range pays one ring start and one dh flush)
-    long grid = 3L * dp_cus();
+    // four rounds of workgroups at three per CU (measured at C3, 768 / 1536 / 3072 workgroups: 3.97 / 3.95 / 3.92 ms -- the CUs do not
+    // finish equal ranges at the same time); never fewer than 4 steps per workgroup (a range pays one ring start and one dh flush)
+    long grid = 12L * dp_cus();
     if (const char* e = getenv("NRM_DP_GRID")) { const long v = atol(e); if (v > 0) grid = v; }
     if (grid > p.steps / 4) grid = p.steps / 4;
     if (grid < 1) grid = 1;

@@ -548,8 +548,11 @@ def _wait_for_foreign_chain(z_elems):
 
 
 # fp32 backward of the bilinear term: the dP walk (one contraction for dt AND dh + the dW_p-only pass) instead of the two E-form
-# passes.  NRM_BWD_DP=1 forces it wherever the library has it (D % 4 == 0, H >= 16), =0 never; default: by size (DP_MIN_ELEMS).
-DP_MIN_ELEMS = 1 << 62
+# passes.  NRM_BWD_DP=1 forces it wherever the library has it (D % 4 == 0, H >= 16), =0 never; default: by size (DP_MIN_ELEMS z elements).
+# Measured per attention (ms, dP + dW_p-only against (b,t) + (b,h), same box): C3 3.98 + 4.06 against 4.38 + 4.04; C5 19.0 + 19.9 against
+# 20.5 + 20.1; C2's shape in fp32 0.60 + 0.63 against 0.72 + 0.62; the reference's default sizes (49 M elements) 0.085 + 0.073 against
+# 0.080 + 0.079 -- equal, and one launch (the W_p^T pack) more: the E-form stays there.
+DP_MIN_ELEMS = 100_000_000
 
 
 def _use_dp_walk(lib, B, T, H, D, mma):

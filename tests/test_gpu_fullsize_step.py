@@ -29,7 +29,7 @@ from oracle import user_model_oracle as orc
 pytestmark = pytest.mark.gpu
 FWD_TOL, GRAD_TOL = 1e-3, 1e-2
 B, H, T, D = 1024, 50, 30, 400
-PATH_ENVS = ("NRM_FE_SORT", "NRM_WGRAD_STREAM", "NRM_BRANCH_STREAMS")
+PATH_ENVS = ("NRM_FE_SORT", "NRM_WGRAD_STREAM", "NRM_BRANCH_STREAMS", "NRM_BWD_DP")
 EPS32 = float(np.finfo(np.float32).eps)
 # Error model of the self-comparisons.  Every weight-gradient entry is a sum over the R = B*T head rows (x H for the attention
 # weights, whose per-row terms are themselves sums) evaluated in fp32; two orders of such a sum (float atomics, split slabs,
@@ -203,6 +203,7 @@ def test_full_size_c3_train_step_big_batch_paths_match_their_small_batch_forms(l
     monkeypatch.setenv("NRM_FE_SORT", "0")
     monkeypatch.setenv("NRM_WGRAD_STREAM", "0")
     monkeypatch.setenv("NRM_BRANCH_STREAMS", "0")
+    monkeypatch.setenv("NRM_BWD_DP", "0")                      # (the label attention's dt / dh by the two E-form passes, not the dP walk)
     small, sopt = fresh()
     out_s, loss_s, g_s = grads_of_first_step(small, sopt, defer=False)
     assert torch.allclose(out_b, out_s, rtol=1e-5, atol=1e-6)
@@ -283,6 +284,7 @@ def test_full_size_c3_train_step_big_batch_paths_match_their_small_batch_forms(l
         monkeypatch.setenv("NRM_FE_SORT", "0")
         monkeypatch.setenv("NRM_WGRAD_STREAM", "0")
         monkeypatch.setenv("NRM_BRANCH_STREAMS", "0")
+        monkeypatch.setenv("NRM_BWD_DP", "0")
         ls, g_step = step_by_hand(small, sopt, False)
         for e in PATH_ENVS:
             monkeypatch.delenv(e, raising=False)
