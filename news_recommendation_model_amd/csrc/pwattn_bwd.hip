@@ -781,6 +781,151 @@ __global__ __launch_bounds__(256, (MMA && KT > 4) || (MMA == 2 && WITH_DW && WIT
 }
 
 // ---------------------------------------------------------------------------------------------
+// (2a) the dW_p-only pass in fp32 with ONE accumulator set (round 5).  bwd_e_kernel<..., WITH_DT = false> forms E_g = X_g^T Y_g per
+// group in one accumulator set and then adds E_g (.) srow_g to dW_p in a second one: 200 accumulator registers (two waves per
+// SIMD) and 100 four-wide FMAs between the MFMA streams of two groups.  But dW_p[k,d] = sum_g sum_r X_g[r,k] (Y_g[r,d] srow_g[d])
+// is ONE long reduction over (g, r) once the scale row is folded into the B operand (5 multiplies per reduction step, the
+// forward's P = t (.) h): a single accumulator set (three waves per SIMD), no per-group epilogue, and the operand prefetch
+// (two steps ahead) runs straight across group boundaries.  Same decomposition, grid and slab layout as bwd_e_kernel.
+// Needs >= NSET reduction steps per group (the scale row of the group whose operands are being requested is held beside the one
+// being consumed: the request pointer may be one group ahead, not two); the launcher keeps bwd_e_kernel for fewer.
+#ifndef DW_SETS
+#define DW_SETS 4          // tuning: operand register sets = reduction steps requested ahead
+#endif
+#ifndef DW_WPE
+#define DW_WPE 3           // tuning: launch bound, waves per SIMD
+#endif
+template <int KT, int DT, bool EXACT, int NSET = DW_SETS>
+__global__ __launch_bounds__(256, DW_WPE) void bwd_dw_direct_kernel(const BwdEParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int D = p.D, R = p.R;
+    // XCD-aware block order, as bwd_e_kernel
+    const int nblk = gridDim.x * gridDim.y;
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = lin & 7;
+    const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+    const int dcol = logical % p.ndcol;
+    int kw, sgrp;
+    if (p.order == 1) {
+        const int nsg = nblk / (p.ndcol * p.nkw);
+        sgrp = (logical / p.ndcol) % nsg;
+        kw = logical / (p.ndcol * nsg);
+    } else {
+        kw = (logical / p.ndcol) % p.nkw;
+        sgrp = logical / (p.ndcol * p.nkw);
+    }
+    const int d0 = dcol * (DT * 16);
+    const int k0 = kw * (KT * 16);
+    const int split = sgrp * 4 + wave;
+    if (split >= p.nsplit) return;
+    int g_lo = split * p.gps, g_step = 1;
+    int g_hi = min(p.G, g_lo + p.gps);
+    if (p.interleave) {
+        const int nact = min(4, p.nsplit - sgrp * 4);
+        g_lo = sgrp * 4 * p.gps + wave; g_step = nact;
+        g_hi = min(p.G, (sgrp * 4 + nact) * p.gps);
+    }
+    const int nsteps = (R + 3) >> 2;                                     // >= 2 (launcher)
+
+    constexpr unsigned OOB = 0x80000000u;
+    const unsigned vx4 = (EXACT || k0 + 4 * r16 < D) ? (unsigned)((long)q * p.xrs + k0 + 4 * r16) * 4u : OOB;
+    const unsigned vx1 = (EXACT || k0 + 64 + r16 < D) ? (unsigned)((long)q * p.xrs + k0 + 64 + r16) * 4u : OOB;
+    const unsigned vy4 = (EXACT || d0 + 4 * r16 < D) ? (unsigned)((long)q * p.yrs + d0 + 4 * r16) * 4u : OOB;
+    const unsigned vy1 = (EXACT || d0 + 64 + r16 < D) ? (unsigned)((long)q * p.yrs + d0 + 64 + r16) * 4u : OOB;
+    const unsigned xbytes = (unsigned)(((long)(R - 1) * p.xrs + D) * 4);
+    const unsigned ybytes = (unsigned)(((long)(R - 1) * p.yrs + D) * 4);
+    const int xstep = (int)(p.xrs * 16), ystep = (int)(p.yrs * 16);     // 4 rows, bytes
+    const int s4off = (EXACT || d0 + 4 * r16 < D) ? d0 + 4 * r16 : 0;   // this lane's columns of a scale row (clamped: the product is
+    const int s1off = (EXACT || d0 + 64 + r16 < D) ? d0 + 64 + r16 : 0; // with an operand that reads 0 there)
+
+    f32x4 dW[KT][DT];
+#pragma unroll
+    for (int it = 0; it < KT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < DT; ++jt) dW[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (g_lo < g_hi) {
+        float a[NSET][KT], b[NSET][DT];                                 // operand register sets (round-robin, no copies)
+        float sr_cur[DT], sr_nxt[DT];                                   // scale rows: group being consumed / group being requested
+        __amdgpu_buffer_rsrc_t rx, ry;
+        int lg = g_lo, ls = 0;                                          // request pointer: (group, step); lg >= g_hi: nothing left
+        auto open_group = [&](int gg) {
+            const int g1 = gg / p.G2, g2 = gg - g1 * p.G2;
+            rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X + (long)g1 * p.xs1 + (long)g2 * p.xs2), 0, xbytes, 0x00020000);
+            ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Y + (long)g1 * p.ys1), 0, ybytes, 0x00020000);
+            const float* srow = p.srow + (long)gg * p.lds_;
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(srow + s4off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sr_nxt[e] = s4[e];
+            if (DT > 4) sr_nxt[4] = srow[s1off];
+        };
+        // request the operands of the step under the request pointer into (a, b), advance the pointer
+        auto request = [&](float (&a)[KT], float (&b)[DT]) {
+            if (lg >= g_hi) return;
+            if (ls == 0) open_group(lg);
+            const u32x4 va = __builtin_amdgcn_raw_buffer_load_b128(rx, vx4, ls * xstep, 0);
+            const u32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(ry, vy4, ls * ystep, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] = __uint_as_float(va[e]); b[e] = __uint_as_float(vb[e]); }
+            if (KT > 4) a[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx1, ls * xstep, 0));
+            if (DT > 4) b[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, vy1, ls * ystep, 0));
+            if (++ls == nsteps) { ls = 0; lg += g_step; }
+        };
+        int cs = 0;                                                      // step of the group being consumed
+        auto consume = [&](const float (&a)[KT], const float (&b)[DT]) {
+            if (cs == 0) {
+#pragma unroll
+                for (int jt = 0; jt < DT; ++jt) sr_cur[jt] = sr_nxt[jt];
+            }
+            float bs[DT];
+#pragma unroll
+            for (int jt = 0; jt < DT; ++jt) bs[jt] = b[jt] * sr_cur[jt];
+#pragma unroll
+            for (int it = 0; it < 4; ++it)                              // fed by the two 16-byte loads
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) dW[it][jt] = mfma16(a[it], bs[jt], dW[it][jt]);
+#pragma unroll
+            for (int it = 0; it < KT; ++it)
+#pragma unroll
+                for (int jt = (it < 4 ? 4 : 0); jt < DT; ++jt) dW[it][jt] = mfma16(a[it], bs[jt], dW[it][jt]);
+            if (++cs == nsteps) cs = 0;
+        };
+        const int ngroups = (g_hi - g_lo + g_step - 1) / g_step;
+        const int total = ngroups * nsteps;
+#pragma unroll
+        for (int u = 0; u < NSET; ++u) request(a[u], b[u]);
+        for (int n = 0; n < total; n += NSET) {
+#pragma unroll
+            for (int u = 0; u < NSET; ++u)
+                if (u == 0 || n + u < total) {
+                    consume(a[u], b[u]);
+                    request(a[u], b[u]);
+                }
+        }
+    }
+
+    // slab layout is TRANSPOSED: ws[split][d][k] (as bwd_e_kernel)
+    float* wsp = p.ws + (long)split * D * D;
+#pragma unroll
+    for (int jt = 0; jt < DT; ++jt) {
+        const int d = d0 + tile_col(jt, r16);
+        if (!(EXACT || d < D)) continue;
+        float* row = wsp + (long)d * D + k0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int kk = 16 * q + 4 * e;
+            if (EXACT || k0 + kk < D)
+                *reinterpret_cast<f32x4*>(row + kk) = f32x4{dW[0][jt][e], dW[1][jt][e], dW[2][jt][e], dW[3][jt][e]};
+        }
+        if (KT > 4 && (EXACT || k0 + 64 + 4 * q < D)) *reinterpret_cast<f32x4*>(row + 64 + 4 * q) = dW[KT - 1][jt];
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 // (2b) software-pipelined variant of the contraction WITHOUT dW_p (the dh pass).  The epilogue of a group
 // (LDS reads of W_p^T, FMAs, row reduction, bounce, atomics) costs several times its instruction time when it
 // runs as one serial block between two MFMA streams (DESIGN.md "stamp findings").  Here a wave keeps TWO
@@ -1188,8 +1333,13 @@ static hipError_t launch_e_t(BwdEParams p, const BwdEPlan& pl, bool with_dw, int
 #undef NRM_LAUNCH_E
         return hipGetLastError();
     }
-    if (with_dw && !p.with_dt) {                        // fp32, dW_p only (no row gradient wanted)
+    if (with_dw && !p.with_dt) {                        // fp32, dW_p only (no row gradient wanted, or beside the dP walk)
         if (p.x_hl4) return hipErrorInvalidValue;
+        const char* e = getenv("NRM_DW_DIRECT");        // (read per launch: tests switch forms inside one process)
+        if (!(e && e[0] == '0') && (p.R + 3) / 4 >= DW_SETS) { // one accumulator set, the scale row folded into the operand
+            if (exact) hipLaunchKernelGGL((bwd_dw_direct_kernel<KT, DT, true>), grid, block, 0, st, p);
+            else       hipLaunchKernelGGL((bwd_dw_direct_kernel<KT, DT, false>), grid, block, 0, st, p);
+        } else
         if (exact) hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, true, 0, false, false>), grid, block, 0, st, p);
         else       hipLaunchKernelGGL((bwd_e_kernel<KT, DT, KS_DW, true, false, 0, false, false>), grid, block, 0, st, p);
     } else if (with_dw) {

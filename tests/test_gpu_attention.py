@@ -205,6 +205,51 @@ def test_dp_walk_backward_matches_oracle_and_e_form(lib, monkeypatch, B, T, H, D
             assert rel_err(got[k], eform[k]) < 2e-5, (grid, k, rel_err(got[k], eform[k]))
 
 
+# the dW_p-only pass with ONE accumulator set (bwd_dw_direct_kernel, round 5: the scale row t[b,t,:] folded into the h operand, one long
+# reduction over (group, row)) against the two-set E-form (NRM_DW_DIRECT=0) and the oracle: as the text+image attention runs it (no row
+# gradient wanted) and beside the dP walk; 5x5 and 4x4 tiles, exact and ragged widths, odd step counts, H <= 4 (one reduction step per
+# group: the launcher keeps the E-form), the interleaved group walk of big groups
+@pytest.mark.parametrize("rowgrads", [False, True])
+@pytest.mark.parametrize("B,T,H,D", [(2, 30, 50, 400), (3, 7, 19, 72), (2, 15, 200, 64), (1, 64, 128, 768), (7, 5, 37, 100), (5, 1, 3, 64),
+                                     (1, 3, 1, 128), (2, 9, 21, 320), (1, 5, 17, 388), (4, 6, 5, 256), (2, 3, 8, 160), (33, 2, 17, 208)])
+def test_direct_dw_pass_matches_oracle_and_e_form(lib, monkeypatch, rowgrads, B, T, H, D):
+    from news_recommendation_model_amd import ops
+    rng = np.random.default_rng(B * 1000 + T * 100 + H * 10 + D + 9)
+    w = _weights(rng, D)
+    tgt = rng.standard_normal((B, T, D)).astype(np.float32)
+    his = rng.standard_normal((B, H, D)).astype(np.float32)
+    gs = rng.standard_normal((B, T, H)).astype(np.float32)
+    if rowgrads:
+        if not lib.nrm_pwattn_bwd_dp_supported(D, H):
+            pytest.skip("no dP walk for this shape: the dW_p-only pass never runs beside it")
+        monkeypatch.setenv("NRM_BWD_DP", "1")
+
+    def run():
+        wg = {k: torch.from_numpy(v).cuda().requires_grad_(True) for k, v in w.items()}
+        t_g = torch.from_numpy(tgt).cuda().requires_grad_(rowgrads)
+        h_g = torch.from_numpy(his).cuda().requires_grad_(rowgrads)
+        s = ops.pointwise_attention_scores(t_g, h_g, wg["mlp.fc1.weight"], wg["mlp.fc1.bias"], wg["mlp.fc2.weight"], wg["mlp.fc2.bias"])
+        (s * torch.from_numpy(gs).cuda()).sum().backward()
+        torch.cuda.synchronize()
+        return wg["mlp.fc1.weight"].grad.cpu().numpy()
+
+    monkeypatch.setenv("NRM_DW_DIRECT", "0")
+    g_e = run()
+    monkeypatch.setenv("NRM_DW_DIRECT", "1")
+    g_d = run()
+    for il in ("0", "1"):
+        monkeypatch.setenv("NRM_BT_INTERLEAVE", il)
+        g_i = run()
+        assert rel_err(g_i, g_e) < 2e-5, il
+    p = {"a." + k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in w.items()}
+    s_c = orc.pointwise_attention_scores(p, "a", torch.from_numpy(tgt), torch.from_numpy(his))[..., 0]
+    (s_c * torch.from_numpy(gs)).sum().backward()
+    ref = p["a.mlp.fc1.weight"].grad.numpy()
+    assert rel_err(g_d, ref) < GRAD_TOL
+    assert rel_err(g_d[:, 3 * D:], ref[:, 3 * D:]) < 1e-4                   # the dW_p block itself
+    assert rel_err(g_d, g_e) < 2e-5                                        # the same products, another summation order
+
+
 def test_dp_walk_is_not_offered_where_it_cannot_run(lib):
     assert lib.nrm_pwattn_bwd_dp_supported(400, 15) == 0              # a wave's 16 rows could span three impressions
     assert lib.nrm_pwattn_bwd_dp_supported(66, 50) == 0               # rows that are not 16-byte multiples
