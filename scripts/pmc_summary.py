@@ -75,7 +75,7 @@ fwd = walk if walk else pick("pwattn_fwd_rw_kernel") if (pick("pwattn_fwd_rw_ker
                                       out.get(pick("pwattn_fwd_kernel") or "", {}).get("SQ_WAVE_CYCLES", 0)) else pick("pwattn_fwd_kernel")
 e_kernels = sorted((k for k in out if k.startswith("bwd_e_kernel")), key=lambda k: -out[k].get("SQ_WAVE_CYCLES", 0.0))
 # bwd_e_kernel<KT, DT, KS, WITH_DW, EXACT, MMA, WITH_DT, XHL4>: the fp32 dW_p-only pass (text+image attention) is "<.., 0, false, false>"
-dw = next((k for k in e_kernels if k.endswith(", 0, false, false>")), None)
+dw = pick("bwd_dw_direct_kernel") or next((k for k in e_kernels if k.endswith(", 0, false, false>")), None)    # (round 5: the one-accumulator-set form)
 bt = pick("bwd_dw_r32_kernel") or next((k for k in e_kernels if k != dw and (", true, true" in k or ", true, false" in k)), None)   # dW_p-only form (bf16), or the WITH_DW instantiation = the (b,t) pass
 bh = pick("bwd_e_pipe_kernel") or next((k for k in e_kernels if k not in (bt, dw)), None)
 names = {"nrm_pwattn_fwd": fwd, "nrm_pwattn_bwd_dz": pick("bwd_dz_"), "pwattn_bwd_e_bt": bt, "pwattn_bwd_e_dw": dw, "pwattn_bwd_e_bh": bh,
