@@ -44,6 +44,65 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return fmaf(x * 0.39894228040143267794f, g.e, g.cdf);
 }
 
+// Four GELUs at once on the packed fp32 pipe (v_pk_mul_f32 / v_pk_fma_f32: two lanes' worth of work per issue slot), round 5.  The
+// same evaluation as gelu_parts -- A&S 7.1.26 with the same coefficients -- rearranged so that nothing but the reciprocal, the exponential
+// and |x| is scalar:  he = 0.5 erfc(|x| / sqrt2) = (0.5 poly(t)) t exp2(-x^2 log2(e) / 2),   gelu(x) = x Phi(x) = 0.5 x + |x| (0.5 - he).
+// 9.5 instructions per element instead of 19 (the forward's epilogue evaluates D of them per score; at D = 64 as many issue slots as
+// the contraction itself).  Differs from gelu_f by roundings only (the constants are folded, |x| c |x| c became x^2 c^2).
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ f32x2 gelu_half_erfc2(f32x2 x, f32x2 ax) {
+    const f32x2 t = f32x2{__builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax[0], 1.0f)),
+                          __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax[1], 1.0f))};
+    const f32x2 ea = (x * x) * f32x2{-0.5f * 1.44269504088896340736f, -0.5f * 1.44269504088896340736f};
+    const f32x2 e = f32x2{__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1])};
+    f32x2 p = __builtin_elementwise_fma(f32x2{0.5f * 1.061405429f, 0.5f * 1.061405429f}, t, f32x2{0.5f * -1.453152027f, 0.5f * -1.453152027f});
+    p = __builtin_elementwise_fma(p, t, f32x2{0.5f * 1.421413741f, 0.5f * 1.421413741f});
+    p = __builtin_elementwise_fma(p, t, f32x2{0.5f * -0.284496736f, 0.5f * -0.284496736f});
+    p = __builtin_elementwise_fma(p, t, f32x2{0.5f * 0.254829592f, 0.5f * 0.254829592f});
+    return (p * t) * e;
+}
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+    const f32x2 ax = f32x2{fabsf(x[0]), fabsf(x[1])};
+    const f32x2 he = gelu_half_erfc2(x, ax);
+    return __builtin_elementwise_fma(ax, f32x2{0.5f, 0.5f} - he, x * f32x2{0.5f, 0.5f});
+}
+__device__ __forceinline__ f32x4 gelu4(f32x4 x) {
+    const f32x2 a = gelu2(f32x2{x[0], x[1]}), b = gelu2(f32x2{x[2], x[3]});
+    return f32x4{a[0], a[1], b[0], b[1]};
+}
+// sum_e w[e] * gelu(z[e])
+// (the two pairs one after the other: interleaved, as hipcc schedules them by itself, the pair-aligned temporaries of both are live at
+// once -- 9 spilled registers in the forward kernel, whose launch bound leaves it 128)
+__device__ __forceinline__ float gelu_dot4(f32x4 w, f32x4 z) {
+    const f32x2 a = f32x2{w[0], w[1]} * gelu2(f32x2{z[0], z[1]});
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x2 s = __builtin_elementwise_fma(f32x2{w[2], w[3]}, gelu2(f32x2{z[2], z[3]}), a);
+    return s[0] + s[1];
+}
+// gelu'(x) = Phi(x) + x phi(x),  Phi(x) = 0.5 + copysign(0.5 - he, x),  phi(x) = exp(-x^2 / 2) / sqrt(2 pi): four at once, times g
+__device__ __forceinline__ f32x4 gelu_grad4_times(f32x4 x, f32x4 g) {
+    f32x4 r;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2 xx = f32x2{x[2 * h], x[2 * h + 1]};
+        const f32x2 ax = f32x2{fabsf(xx[0]), fabsf(xx[1])};
+        const f32x2 t = f32x2{__builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax[0], 1.0f)),
+                              __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax[1], 1.0f))};
+        const f32x2 ea = (xx * xx) * f32x2{-0.5f * 1.44269504088896340736f, -0.5f * 1.44269504088896340736f};
+        const f32x2 e = f32x2{__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1])};
+        f32x2 p = __builtin_elementwise_fma(f32x2{0.5f * 1.061405429f, 0.5f * 1.061405429f}, t, f32x2{0.5f * -1.453152027f, 0.5f * -1.453152027f});
+        p = __builtin_elementwise_fma(p, t, f32x2{0.5f * 1.421413741f, 0.5f * 1.421413741f});
+        p = __builtin_elementwise_fma(p, t, f32x2{0.5f * -0.284496736f, 0.5f * -0.284496736f});
+        p = __builtin_elementwise_fma(p, t, f32x2{0.5f * 0.254829592f, 0.5f * 0.254829592f});
+        const f32x2 q = f32x2{0.5f, 0.5f} - (p * t) * e;                 // 0.5 - he >= 0
+        const f32x2 cdf = f32x2{0.5f, 0.5f} + f32x2{copysignf(q[0], xx[0]), copysignf(q[1], xx[1])};
+        const f32x2 d = __builtin_elementwise_fma(xx * f32x2{0.39894228040143267794f, 0.39894228040143267794f}, e, cdf);
+        const f32x2 o = d * f32x2{g[2 * h], g[2 * h + 1]};
+        r[2 * h] = o[0]; r[2 * h + 1] = o[1];
+    }
+    return r;
+}
+
 __device__ __forceinline__ float wave_sum16(float v) {   // sum over the 16 lanes sharing l>>4
     v += __shfl_xor(v, 1);
     v += __shfl_xor(v, 2);

@@ -267,9 +267,7 @@ __global__ __launch_bounds__(RX_WAVES * 64, RT <= 2 ? RX_WAVES / 2 : RX_WAVES / 
                 if (n < p.ldy) store_b128_guarded(__builtin_bit_cast(u32x4, v), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb);
             } else if (EPI == EPI_GELU) {
                 if (n < p.ldz) store_b128_guarded(__builtin_bit_cast(u32x4, v), rs_z, (unsigned)(rl * p.ldz + 4 * q) * 4u, nb);
-                f32x4 g;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = gelu_f(v[e]);
+                const f32x4 g = gelu4(v);
                 if (n < p.ldy) store_b128_guarded(__builtin_bit_cast(u32x4, g), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb);
             } else if (EPI == EPI_MUL) {
                 if (n < p.ldz) store_b128_guarded(__builtin_bit_cast(u32x4, v), rs_z, (unsigned)(rl * p.ldz + 4 * q) * 4u, nb);
@@ -279,9 +277,7 @@ __global__ __launch_bounds__(RX_WAVES * 64, RT <= 2 ? RX_WAVES / 2 : RX_WAVES / 
             } else {
                 f32x4 zz = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (n < p.ldz) zz = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_z, (unsigned)(rl * p.ldz + 4 * q) * 4u, nb, 0));
-                f32x4 g;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = acc[rt][e] * gelu_grad_f(zz[e]);
+                const f32x4 g = gelu_grad4_times(zz, acc[rt]);
                 if (n < p.ldy) store_b128_guarded(__builtin_bit_cast(u32x4, g), rs_y, (unsigned)(rl * p.ldy + 4 * q) * 4u, nb);
             }
         }

@@ -233,11 +233,18 @@ __global__ __launch_bounds__(NW * 64, WPE) void pwattn_fwd_kernel(const FwdParam
         if (NRM_PRIO) __builtin_amdgcn_s_setprio(0);
 
         // --- epilogue of this N-chunk: optional z store ; GELU ; partial fc2 dot
+        // fc2 weights of a tile are requested two tiles ahead of their use, and the tiles are kept in order (scheduling barrier): left
+        // alone hipcc requests all NT of them in front of the first GELU -- 4 NT registers on top of the live accumulators
+        f32x4 wq[3];
+#pragma unroll
+        for (int it = 0; it < 2 && it < NT; ++it)
+            wq[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, 16 * q, (kc0 + it * 16) * 4, 0));   // 0 beyond D
 #pragma unroll
         for (int it = 0; it < NT; ++it) {
             const int kb = (kc0 + it * 16) * 4;
             const bool kok = kc0 + it * 16 + 4 * q < D;
-            const f32x4 ww = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, 16 * q, kb, 0));   // 0 beyond D
+            if (it + 2 < NT) wq[(it + 2) % 3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, 16 * q, kb + 128, 0));
+            const f32x4 ww = wq[it % 3];
 #pragma unroll
             for (int jt = 0; jt < MT; ++jt) {
                 const f32x4 zz = acc[it][jt];
@@ -246,8 +253,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void pwattn_fwd_kernel(const FwdParam
                     store_b128_guarded(__builtin_bit_cast(u32x4, zz), rs_z, vz, kb);
                 }
                 if (NRM_DIAG_FWD & 8) s_part[jt] += ww[0] * zz[0] + ww[1] * zz[1] + ww[2] * zz[2] + ww[3] * zz[3];
-                else s_part[jt] += ww[0] * gelu_f(zz[0]) + ww[1] * gelu_f(zz[1]) + ww[2] * gelu_f(zz[2]) + ww[3] * gelu_f(zz[3]);
+                else s_part[jt] += gelu_dot4(ww, zz);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 

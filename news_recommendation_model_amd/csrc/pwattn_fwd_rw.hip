@@ -240,7 +240,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, FB_WAVES / 4) void pwattn_fwd_rw_ker
             if (SAVE_Z && !(NRM_DIAG_RW & 1) && k0 + it * 16 + 4 * q < D)
                 store_b128_guarded(__builtin_bit_cast(u32x4, zz), rs_z, (unsigned)(r16 * D + 4 * q) * 4u, (k0 + it * 16) * 4);
             if (NRM_DIAG_RW & 2) s_part += ww[it][0] * zz[0] + ww[it][1] * zz[1] + ww[it][2] * zz[2] + ww[it][3] * zz[3];
-            else s_part += ww[it][0] * gelu_f(zz[0]) + ww[it][1] * gelu_f(zz[1]) + ww[it][2] * gelu_f(zz[2]) + ww[it][3] * gelu_f(zz[3]);
+            else s_part += gelu_dot4(ww[it], zz);
         }
         const float v = sum_rows4(s_part) + b2;
         if (q == 0 && m < M) {
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(512, 2) void pwattn_fwd_walk_kernel(const FwdParams
                 const f32x4 ww = wws[it & 1];
                 if (it + 2 < NTS) load_vw(it + 2, it & 1);
                 if (SAVE_Z) store_b128_guarded(__builtin_bit_cast(u32x4, zz), rs_z, vz, t * H * D * 4 + it * 64);
-                s_part += ww[0] * gelu_f(zz[0]) + ww[1] * gelu_f(zz[1]) + ww[2] * gelu_f(zz[2]) + ww[3] * gelu_f(zz[3]);
+                s_part += gelu_dot4(ww, zz);
                 __builtin_amdgcn_sched_barrier(0);
             }
             const float sv = sum_rows4(s_part) + b2;
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(512, 2) void pwattn_fwd_walk_f32_kernel(const FwdPa
                 const f32x4 zz = acc[it] + vreg[it];
                 if (SAVE_Z) store_b128_guarded(__builtin_bit_cast(u32x4, zz), rs_z, vz, t * H * D * 4 + it * 64);
                 const f32x4 ww = wreg[it];
-                s_part += ww[0] * gelu_f(zz[0]) + ww[1] * gelu_f(zz[1]) + ww[2] * gelu_f(zz[2]) + ww[3] * gelu_f(zz[3]);
+                s_part += gelu_dot4(ww, zz);
                 __builtin_amdgcn_sched_barrier(0);
             }
             const float sv = sum_rows4(s_part) + b2;
