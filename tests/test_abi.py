@@ -45,6 +45,22 @@ def test_resident_w_backward_plan(lib):
     assert rc != 0 and b"NRM_DZ_HL4" in lib.nrm_last_error()                  # only the dW_p-only pass (4) reads NRM_DZ_HL4
 
 
+def test_dp_walk_backward_plan(lib):
+    # fp32 dP walk (round 5): histories of at least 16 rows, widths that are 16-byte multiples; the packed W_p^T image covers whole N-chunks
+    assert lib.nrm_pwattn_bwd_dp_supported(400, 50) == 1 and lib.nrm_pwattn_bwd_dp_supported(64, 200) == 1
+    assert lib.nrm_pwattn_bwd_dp_supported(400, 15) == 0 and lib.nrm_pwattn_bwd_dp_supported(66, 50) == 0
+    assert lib.nrm_pwattn_bwd_dp_packed_floats(400, 50) == 25 * (2 * 13 * 16) * 16       # 25 K-chunks x two N-chunks of 13 tiles
+    assert lib.nrm_pwattn_bwd_dp_packed_floats(768, 128) == 48 * (4 * 12 * 16) * 16      # four N-chunks of 12 tiles
+    assert lib.nrm_pwattn_bwd_dp_packed_floats(64, 200) == 4 * (1 * 4 * 16) * 16
+    assert lib.nrm_pwattn_bwd_dp_packed_floats(400, 8) == 0
+    rc = lib.nrm_pwattn_bwd_dp_dtdh(None, None, None, None, None, None, 2, 3, 50, 400, None)
+    assert rc != 0 and b"null" in lib.nrm_last_error()
+    rc = lib.nrm_pwattn_bwd_dp_dtdh(None, None, None, None, None, None, 2, 3, 8, 400, None)
+    assert rc != 0
+    rc = lib.nrm_pwattn_bwd_dp_pack(None, 1600, 400, 50, None, None)
+    assert rc != 0 and b"null" in lib.nrm_last_error()
+
+
 def test_host_validation_rejects_bad_shapes(lib):
     # null pointers / bad D are refused on the host before any launch
     rc = lib.nrm_pwattn_fwd(None, None, None, None, None, None, None, None, None, 2, 3, 4, 66, 0, None)
